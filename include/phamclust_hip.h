@@ -1,0 +1,143 @@
+/*
+ * phamclust_hip.h -- C-ABI of libphamclust_hip.so: the MI355X (gfx950) implementation of
+ * phamclust's pairwise genome-similarity matrix fill.
+ *
+ * The reference (chg60/phamclust, pure Python) has no FFI; the operator boundary this
+ * library sits behind is
+ *     matrix_de_novo(genomes, func, cpus, as_distance=True) -> SymMatrix
+ *                                   /root/reference/src/phamclust/matrix.py:432-497
+ *     METRICS = {"gcs","jc","pocp","af","aai","peq"} -> f(source, target, as_distance)
+ *                                   /root/reference/src/phamclust/cli.py:30-35
+ *                                   /root/reference/src/phamclust/metrics.py:26-253
+ * The entry points below are what a ctypes binding for that boundary calls
+ * (INTEGRATION.md shows the stub).  Plain pointers and sizes only; no exceptions or
+ * aborts cross this boundary: every function returns 0 or a negative pc_status and
+ * leaves a message for pc_last_error().
+ *
+ * Threading: one host thread drives one pc_ctx; one pc_ctx drives one GPU
+ * (one process per GPU; multi-GPU = one ctx per rank + pc_set_shard, the exchange is the
+ * caller's single RCCL gather of the shard buffers).
+ */
+#ifndef PHAMCLUST_HIP_H
+#define PHAMCLUST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_VERSION 100   /* 0.1.0 */
+
+typedef enum {
+    PC_OK = 0,
+    PC_ERR_ARG = -1,        /* bad argument / inconsistent packed data          */
+    PC_ERR_HIP = -2,        /* a HIP runtime call failed                         */
+    PC_ERR_STATE = -3,      /* call order (e.g. fill before upload)              */
+    PC_ERR_LIMIT = -4,      /* problem exceeds an implementation limit           */
+    PC_ERR_DATA = -5        /* data the reference cannot process either (empty translation under aai/peq) */
+} pc_status;
+
+/* metric ids follow the order of the reference's METRICS dict (cli.py:30-35) */
+typedef enum { PC_GCS = 0, PC_JC = 1, PC_POCP = 2, PC_AF = 3, PC_AAI = 4, PC_PEQ = 5 } pc_metric;
+
+typedef struct pc_ctx pc_ctx;
+
+/*
+ * Packed genomes: host memory, caller-owned, read-only during pc_upload (the library
+ * copies what it needs).  Genome order is the name-sorted list order of
+ * scripts/phamclust.py:221 and fixes pair orientation: for s < t, s is the reference's
+ * `source`, t its `target` (matrix.py:479-486).
+ */
+typedef struct {
+    int32_t n_genomes;          /* N                                                       */
+    int32_t n_phams;            /* P                                                       */
+    int32_t words_per_row;      /* W = max(1, ceil(P/64))                                  */
+    int32_t reserved;           /* must be 0                                               */
+    const uint64_t* bitmap;     /* [N*W] bit (p & 63) of word (p >> 6) of row g: g holds pham p  (Genome.phams keys, genome.py:28) */
+    const int32_t* nph;         /* [N] len(g.phams)                  (metrics.py:46)        */
+    const int32_t* ngen;        /* [N] len(g)                        (genome.py:168-169)    */
+    const int64_t* tlen;        /* [N] sum of len(translation)       (metrics.py:135-147)   */
+    const int64_t* gene_off;    /* [N+1] genes of genome g = [gene_off[g], gene_off[g+1])   */
+    const int32_t* gene_pham;   /* [G] ascending within a genome, paralogs in list order    */
+    const int64_t* seq_off;     /* [G+1] residues of gene k = [seq_off[k], seq_off[k+1])    */
+    const uint8_t* residues;    /* [R] raw bytes, one per character                         */
+} pc_packed;
+
+/* Filled by the fill calls when non-NULL.  Times are HIP-event milliseconds on the
+ * stream the kernels ran on. */
+typedef struct {
+    int64_t n_pairs;            /* genome pairs produced by this call (this rank's shard)   */
+    int64_t n_alignments;       /* ordered sequence pairs aligned (aai/peq), else 0         */
+    int64_t n_cells;            /* sum of la*lb over those alignments                       */
+    int64_t n_tasks;            /* wave tasks launched by the alignment kernels             */
+    int64_t n_residue_bytes;    /* sum of (la+lb) over alignments: algorithmic input bytes  */
+    int32_t n_align_launches;   /* alignment kernel launches                                */
+    int32_t reserved;
+    float ms_total;             /* whole call, device side                                  */
+    float ms_plan;              /* pair walk: counts, scans, bucketing, task build          */
+    float ms_align;             /* alignment kernels only (the dominant kernels)            */
+    float ms_reduce;            /* best-match select + fp64 epilogue (or the set-metric kernel) */
+} pc_stats;
+
+int pc_version(void);
+const char* pc_last_error(void);
+
+/* One context per GPU.  device_id is the HIP device ordinal. */
+int pc_ctx_create(pc_ctx** out, int device_id);
+void pc_ctx_destroy(pc_ctx* ctx);
+
+/* Copy the packed genomes to HBM and build the device-side indices (rank table, gene
+ * table, encoded residues).  Replaces any previous upload. */
+int pc_upload(pc_ctx* ctx, const pc_packed* genomes);
+
+/*
+ * Static shard of the upper-triangular pair list: rank r of `world` owns the pairs
+ * (s, t), s < t, of the target genomes t it is dealt (boustrophedon deal over t, so the
+ * linear cost ramp in t balances).  Default after upload: rank 0 of 1 = every pair.
+ * pc_shard_pairs: pairs owned; pc_shard_stride: max over ranks (equal-count gather size).
+ */
+int pc_set_shard(pc_ctx* ctx, int rank, int world);
+int64_t pc_shard_pairs(const pc_ctx* ctx);
+int64_t pc_shard_stride(const pc_ctx* ctx);
+
+/*
+ * matrix_de_novo's fill (matrix.py:479-491) for the six METRICS, whole matrix, one GPU.
+ * out_condensed: host f64[N(N-1)/2] in scipy condensed order (row-major strict upper
+ * triangle) in packed-genome index space.  Values are already round(x, 6) exactly as
+ * the reference returns them; the diagonal is not produced (matrix.py:467-468 presets it).
+ */
+int pc_fill(pc_ctx* ctx, int metric, int as_distance, double* out_condensed, pc_stats* stats);
+
+/* Same, result left in HBM: out_dev is a device pointer to f64[N(N-1)/2]; `stream` is a
+ * hipStream_t (NULL = the context's own stream).  Asynchronous w.r.t. the host except for
+ * one small plan read-back under aai/peq. */
+int pc_fill_dev(pc_ctx* ctx, int metric, int as_distance, void* out_dev, void* stream, pc_stats* stats);
+
+/* This rank's shard only, shard-local order, into device memory f64[pc_shard_stride()]
+ * (tail beyond pc_shard_pairs() is zero-filled).  Followed by the caller's RCCL gather. */
+int pc_fill_shard_dev(pc_ctx* ctx, int metric, int as_distance, void* shard_dev, void* stream, pc_stats* stats);
+
+/* Root only: permute `world` gathered shards (f64[world * pc_shard_stride()], device)
+ * into scipy condensed order (device f64[N(N-1)/2]). */
+int pc_assemble_dev(pc_ctx* ctx, const void* gathered_dev, int world, void* out_condensed_dev, void* stream);
+
+/*
+ * Test hook for the alignment kernels (replaces parasail.nw_trace_diag_16 +
+ * get_traceback + the two counts read at metrics.py:216-217): aligns gene a_gene[k]
+ * (rows, the reference's seq_a) against gene b_gene[k] (columns, seq_b) of the uploaded
+ * genomes.  n_ident = comp.count("|"), n_diag = aligned (non-gap) columns, so
+ * len(traceback.query) = la + lb - n_diag.  variant: 0 = as pc_fill would choose,
+ * -1 = general fallback kernel, w > 0 = force the systolic kernel with w columns per lane.
+ */
+int pc_align_pairs(pc_ctx* ctx, const int32_t* a_gene, const int32_t* b_gene, int64_t n, int variant,
+                   int32_t* n_ident, int32_t* n_diag);
+
+/* Test hook: the device implementation of Python's round(x, 6) (the rounding every metric
+ * returns through, e.g. metrics.py:50-53) applied to n host doubles in [0, 2^20). */
+int pc_round6_probe(pc_ctx* ctx, const double* in, double* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHAMCLUST_HIP_H */

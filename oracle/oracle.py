@@ -1,0 +1,245 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE ONLY -- see pc_oracle.c header).
+
+Two independent restatements of the reference's hot path live here:
+
+* the C library ``libpc_oracle.so`` (closed forms on packed arrays + the aligner),
+  reached through ctypes;
+* ``py_*`` functions: pure-Python per-pair code over ``Genome``-like objects (anything
+  with ``.phams: dict[str, list[str]]``), written from the reference's per-pair
+  semantics (metrics.py:26-253), for small cases only.
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's cpu_baseline leg may import
+this module.  aai/peq: PARITY UNPINNED vs parasail for co-optimal alignment ties.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpc_oracle.so")
+METRIC_IDS = {"gcs": 0, "jc": 1, "pocp": 2, "af": 3, "aai": 4, "peq": 5}
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+class _Packed(ctypes.Structure):
+    _fields_ = [("n_genomes", ctypes.c_int32), ("n_phams", ctypes.c_int32),
+                ("words_per_row", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("bitmap", _u64p), ("nph", _i32p), ("ngen", _i32p), ("tlen", _i64p),
+                ("gene_off", _i64p), ("gene_pham", _i32p), ("seq_off", _i64p), ("residues", _u8p)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "pc_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.pco_nw_stats.argtypes = [_u8p, ctypes.c_int, _u8p, ctypes.c_int, _i32p, _i32p, _i32p]
+        L.pco_nw_traceback.argtypes = [_u8p, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_char_p,
+                                       ctypes.c_char_p, ctypes.c_char_p, _i32p]
+        L.pco_nw_batch.argtypes = [_u8p, _i64p, _i32p, _i32p, ctypes.c_int64, _i32p, _i32p, _i32p, ctypes.c_int]
+        L.pco_round6.argtypes = [ctypes.c_double]
+        L.pco_round6.restype = ctypes.c_double
+        L.pco_pair.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.pco_pair.restype = ctypes.c_double
+        L.pco_fill.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int]
+        L.pco_fill_rows.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    _f64p, ctypes.c_int, _i64p]
+        L.pco_blosum62.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.pco_map.argtypes = [ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _ptr(arr, typ):
+    return arr.ctypes.data_as(typ)
+
+
+def _as_bytes(seq):
+    return seq if isinstance(seq, (bytes, bytearray)) else seq.encode("latin-1")
+
+
+def nw_stats(seq_a, seq_b):
+    """One-pass formulation -> (score, n_identical, n_diagonal_columns)."""
+    a, b = _as_bytes(seq_a), _as_bytes(seq_b)
+    sc, ni, nd = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    ab = (ctypes.c_uint8 * len(a)).from_buffer_copy(a)
+    bb = (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+    rc = lib().pco_nw_stats(ab, len(a), bb, len(b), ctypes.byref(sc), ctypes.byref(ni), ctypes.byref(nd))
+    if rc != 0:
+        raise ValueError("pco_nw_stats failed (empty sequence?)")
+    return sc.value, ni.value, nd.value
+
+
+class Traceback:
+    """What the reference reads from parasail's ``result.get_traceback(...)``
+    (metrics.py:175, 216-220): ``.query``, ``.comp``, ``.ref``."""
+
+    def __init__(self, query, comp, ref, score):
+        self.query, self.comp, self.ref, self.score = query, comp, ref, score
+
+
+def nw_traceback(seq_a, seq_b):
+    """Table + traceback formulation -> :class:`Traceback`."""
+    a, b = _as_bytes(seq_a), _as_bytes(seq_b)
+    n = len(a) + len(b) + 1
+    q, c, r = ctypes.create_string_buffer(n), ctypes.create_string_buffer(n), ctypes.create_string_buffer(n)
+    sc = ctypes.c_int32()
+    ab = (ctypes.c_uint8 * len(a)).from_buffer_copy(a)
+    bb = (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+    length = lib().pco_nw_traceback(ab, len(a), bb, len(b), q, c, r, ctypes.byref(sc))
+    if length < 0:
+        raise ValueError("pco_nw_traceback failed (empty sequence?)")
+    return Traceback(q.raw[:length].decode("latin-1"), c.raw[:length].decode("latin-1"),
+                     r.raw[:length].decode("latin-1"), sc.value)
+
+
+def nw_batch(residues, seq_off, a_idx, b_idx, nthreads=0):
+    """(score, n_ident, n_diag) int32 arrays for gene-index pairs into a packed residue buffer."""
+    a_idx = np.ascontiguousarray(a_idx, dtype=np.int32)
+    b_idx = np.ascontiguousarray(b_idx, dtype=np.int32)
+    n = a_idx.shape[0]
+    sc, ni, nd = (np.zeros(n, np.int32) for _ in range(3))
+    rc = lib().pco_nw_batch(_ptr(residues, _u8p), _ptr(seq_off, _i64p), _ptr(a_idx, _i32p), _ptr(b_idx, _i32p),
+                            n, _ptr(sc, _i32p), _ptr(ni, _i32p), _ptr(nd, _i32p), nthreads)
+    if rc != 0:
+        raise ValueError("pco_nw_batch failed")
+    return sc, ni, nd
+
+
+def round6(x):
+    return lib().pco_round6(float(x))
+
+
+def _struct(packed):
+    s = _Packed(packed.n_genomes, packed.n_phams, packed.words_per_row, 0,
+                _ptr(packed.bitmap, _u64p), _ptr(packed.nph, _i32p), _ptr(packed.ngen, _i32p),
+                _ptr(packed.tlen, _i64p), _ptr(packed.gene_off, _i64p), _ptr(packed.gene_pham, _i32p),
+                _ptr(packed.seq_off, _i64p), _ptr(packed.residues, _u8p))
+    return s
+
+
+def pair(packed, metric, s, t, as_distance=True):
+    return lib().pco_pair(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), s, t)
+
+
+def fill(packed, metric, as_distance=True, nthreads=0):
+    """Condensed (scipy order) f64 vector of the N(N-1)/2 pair values."""
+    out = np.zeros(packed.n_genomes * (packed.n_genomes - 1) // 2, dtype=np.float64)
+    rc = lib().pco_fill(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), _ptr(out, _f64p), nthreads)
+    if rc != 0:
+        raise RuntimeError("pco_fill failed")
+    return out
+
+
+def fill_rows(packed, metric, row_begin, row_end, as_distance=True, nthreads=0):
+    """Rows [row_begin,row_end) only (bounded CPU-baseline sample).  Returns (condensed, n_aln, n_cells)."""
+    out = np.zeros(packed.n_genomes * (packed.n_genomes - 1) // 2, dtype=np.float64)
+    stats = np.zeros(2, dtype=np.int64)
+    rc = lib().pco_fill_rows(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), row_begin, row_end,
+                             _ptr(out, _f64p), nthreads, _ptr(stats, _i64p))
+    if rc != 0:
+        raise RuntimeError("pco_fill_rows failed")
+    return out, int(stats[0]), int(stats[1])
+
+
+def n_threads():
+    return lib().pco_threads()
+
+
+# ---------------------------------------------------------------------------
+# Pure-Python per-pair restatement (small cases).  Each function follows the
+# reference function of the same role; nothing is imported from the reference.
+# ---------------------------------------------------------------------------
+def _finish(similarity, as_distance):
+    return round(1.0 - similarity, 6) if as_distance else round(similarity, 6)
+
+
+def _shared(source, target):
+    return set(source.phams) & set(target.phams)
+
+
+def _n_genes(genome):
+    return sum(len(v) for v in genome.phams.values())
+
+
+def py_gcs(source, target, as_distance=False):          # metrics.py:26-53
+    shared = _shared(source, target)
+    sim = 0.0 if not shared else 2.0 * len(shared) / (len(source.phams) + len(target.phams))
+    return _finish(sim, as_distance)
+
+
+def py_jc(source, target, as_distance=False):           # metrics.py:56-80
+    shared = _shared(source, target)
+    sim = 0.0 if not shared else len(shared) / len(set(source.phams) | set(target.phams))
+    return _finish(sim, as_distance)
+
+
+def py_pocp(source, target, as_distance=False):         # metrics.py:83-115
+    shared = _shared(source, target)
+    if not shared:
+        return _finish(0.0, as_distance)
+    conserved = sum(len(source.phams[p]) for p in shared) + sum(len(target.phams[p]) for p in shared)
+    return _finish(conserved / (_n_genes(source) + _n_genes(target)), as_distance)
+
+
+def py_af(source, target, as_distance=False):           # metrics.py:118-157
+    shared = _shared(source, target)
+    if not shared:
+        return _finish(0.0, as_distance)
+    conserved = total = 0
+    for genome in (source, target):
+        for pham, translations in genome.phams.items():
+            for translation in translations:
+                if pham in shared:
+                    conserved += len(translation)
+                total += len(translation)
+    return _finish(conserved / total, as_distance)
+
+
+def py_aai(source, target, ppos=False, as_distance=False):   # metrics.py:178-232
+    shared = _shared(source, target)
+    if not shared:
+        return _finish(0.0, as_distance)
+    identities, lengths = [], []
+    for pham in sorted(shared):
+        anchors, others = source.phams[pham], target.phams[pham]
+        if len(anchors) > len(others):
+            anchors, others = others, anchors
+        for anchor in anchors:
+            candidates = []
+            for other in others:
+                tb = nw_traceback(anchor, other)
+                hits = float(tb.comp.count("|")) + (float(tb.comp.count("+")) if ppos else 0.0)
+                candidates.append((hits / len(tb.query), len(tb.query)))
+            best = sorted(candidates, key=lambda c: c[0])[-1]
+            identities.append(best[0])
+            lengths.append(best[1])
+    sim = float(sum([x * w for x, w in zip(identities, lengths)])) / sum(lengths)
+    return _finish(sim, as_distance)
+
+
+def py_peq(source, target, as_distance=False):          # metrics.py:235-253
+    sim = py_af(source, target) * py_aai(source, target)
+    return _finish(sim, as_distance)
+
+
+PY_METRICS = {"gcs": py_gcs, "jc": py_jc, "pocp": py_pocp, "af": py_af, "aai": py_aai, "peq": py_peq}

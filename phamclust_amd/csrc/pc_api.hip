@@ -1,0 +1,524 @@
+// pc_api.hip -- C-ABI of libphamclust_hip.so (include/phamclust_hip.h): context, upload,
+// shard bookkeeping and the orchestration of the fill (matrix.py:432-497's hot loop).
+//
+// Fill plan for aai/peq (all on one stream, one small read-back in the middle):
+//   1 COUNT walk     per pair: alignments; per column gene: bucket sizes; totals
+//   2 scans          pair -> first result slot; gene -> bucket start; gene -> first task
+//   3 read-back      alignment total + task range per kernel variant (a few words)
+//   4 ENUM walk      (row gene, result slot) scattered into the column gene's bucket
+//   5 K4 launches    one per kernel variant present, wave tasks of <= 64 row sequences
+//   6 REDUCE walk    best match per anchor gene, fp64 weighted mean, af, round -> out
+// Bucketing by column gene is what lets a wave build one substitution profile and stream
+// many row sequences through it; results are written pair-major so step 6 reads them
+// contiguously and in the canonical order (pham id, anchor gene, other gene).
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "pc_common.h"
+#include "../../include/phamclust_hip.h"
+
+static thread_local char g_err[512] = "";
+void pc_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* pc_last_error(void) { return g_err; }
+extern "C" int pc_version(void) { return PC_VERSION; }
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return PC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { pc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return PC_ERR_HIP; }
+        cap = want; return PC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+template <class T> int upload_vec(DevBuf& b, const std::vector<T>& v) {
+    int rc = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+    if (rc != PC_OK) return rc;
+    if (!v.empty()) PC_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PC_OK;
+}
+
+}  // namespace
+
+struct pc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool uploaded = false;
+    PcDev dev{};
+    std::vector<int32_t> h_gene_len;
+    int max_gene_len = 0, min_gene_len = 0;
+    // kernel-variant classes over column genes
+    std::vector<int> cls_variant;           // per class: variant id, -1 = general kernel
+    std::vector<int32_t> cls_begin;         // [ncls+1] positions in class order
+    std::vector<int> cls_max_lb;
+    // shard
+    int rank = 0, world = 1;
+    int64_t shard_pairs = 0, shard_stride = 0;
+    PcShard shard{};
+    // persistent device arrays
+    DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
+    DevBuf b_cls_order, b_cls_idx, b_owned, b_lbase;
+    // work buffers (grow-only)
+    DevBuf b_na, b_off, b_col_cnt, b_col_start, b_col_cur, b_cnt_q, b_start_q, b_ntask_q, b_task_off_q, b_scan_tmp;
+    DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out;
+    uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+static int set_device(pc_ctx* c) { PC_HIP(hipSetDevice(c->device)); return PC_OK; }
+
+extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
+    if (!out) { pc_set_error("pc_ctx_create: out is NULL"); return PC_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    PC_HIP(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) { pc_set_error("pc_ctx_create: device %d of %d", device_id, n); return PC_ERR_ARG; }
+    pc_ctx* c = new (std::nothrow) pc_ctx();
+    if (!c) { pc_set_error("out of host memory"); return PC_ERR_ARG; }
+    c->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_plan, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) { pc_set_error("pc_ctx_create: %s", hipGetErrorString(e)); pc_ctx_destroy(c); return PC_ERR_HIP; }
+    *out = c;
+    return PC_OK;
+}
+
+extern "C" void pc_ctx_destroy(pc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
+                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_cls_order, &c->b_cls_idx, &c->b_owned, &c->b_lbase,
+                      &c->b_na, &c->b_off, &c->b_col_cnt, &c->b_col_start, &c->b_col_cur, &c->b_cnt_q, &c->b_start_q,
+                      &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_bucket_row, &c->b_bucket_dest,
+                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out};
+    for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->h_plan) (void)hipHostFree(c->h_plan);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// residue byte -> code.  Alphabet letters (either case) -> 0..23 in BLOSUM62 order; every
+// other byte value keeps its own identity (codes 24..229, ASCII case folded) and scores as '*'.
+static void build_code_lut(uint8_t lut[256]) {
+    static const char alpha[] = "ARNDCQEGHILKMFPSTWYVBZX*";
+    int assigned[256];
+    for (int i = 0; i < 256; ++i) assigned[i] = -1;
+    for (int k = 0; k < 24; ++k) assigned[(unsigned char)alpha[k]] = k;
+    int next = 24;
+    for (int v = 0; v < 256; ++v) {
+        if (v >= 'a' && v <= 'z') continue;
+        if (assigned[v] < 0) assigned[v] = next++;
+    }
+    for (int v = 'a'; v <= 'z'; ++v) assigned[v] = assigned[v - 32];
+    for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)assigned[i];
+}
+
+static int apply_shard(pc_ctx* c, int rank, int world) {
+    const int N = c->dev.N;
+    std::vector<int32_t> owned; std::vector<int64_t> lbase;
+    int64_t best = 0;
+    for (int r = 0; r < world; ++r) {
+        int64_t tot = 0;
+        for (int j = 0;; ++j) {
+            const int pos = (j & 1) ? world - 1 - r : r;
+            const int64_t t = (int64_t)j * world + pos;
+            if (t >= N) { if ((int64_t)j * world >= N) break; else continue; }
+            if (r == rank) { owned.push_back((int32_t)t); lbase.push_back(tot); }
+            tot += t;
+        }
+        if (r == rank) { lbase.push_back(tot); c->shard_pairs = tot; }
+        best = std::max(best, tot);
+    }
+    c->shard_stride = best;
+    c->rank = rank; c->world = world;
+    int rc = upload_vec(c->b_owned, owned); if (rc != PC_OK) return rc;
+    rc = upload_vec(c->b_lbase, lbase); if (rc != PC_OK) return rc;
+    c->shard.nown = (int32_t)owned.size();
+    c->shard.owned = c->b_owned.as<int32_t>();
+    c->shard.lbase = c->b_lbase.as<int64_t>();
+    return PC_OK;
+}
+
+extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
+    if (!c || !g) { pc_set_error("pc_upload: NULL argument"); return PC_ERR_ARG; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    const int N = g->n_genomes, P = g->n_phams, W = g->words_per_row;
+    if (N <= 0 || P < 0 || W != std::max(1, (P + 63) / 64) || g->reserved != 0 || !g->bitmap || !g->nph || !g->ngen || !g->tlen ||
+        !g->gene_off || !g->seq_off) {
+        pc_set_error("pc_upload: inconsistent header (N=%d P=%d W=%d)", N, P, W); return PC_ERR_ARG;
+    }
+    const int64_t G64 = g->gene_off[N];
+    if (G64 < 0 || G64 > 0x7fffffffLL || g->gene_off[0] != 0 || (G64 > 0 && (!g->gene_pham || !g->residues))) {
+        pc_set_error("pc_upload: bad gene table"); return PC_ERR_ARG;
+    }
+    const int G = (int)G64;
+    c->uploaded = false;
+    PC_HIP(hipStreamSynchronize(c->stream));
+
+    // ---- host-side indices -------------------------------------------------------
+    const int Wstride = W | 1;
+    std::vector<uint64_t> bitmap((size_t)N * Wstride, 0);
+    std::vector<uint32_t> rankpre((size_t)N * W);
+    std::vector<int32_t> ent_cnt, ent_len, ent_gene, gene_len(G);
+    std::vector<int64_t> gene_off(G);
+    ent_cnt.reserve(G); ent_len.reserve(G); ent_gene.reserve(G);
+    int64_t code_bytes = 0;
+    int maxlen = 0, minlen = G ? 0x7fffffff : 0;
+    for (int k = 0; k < G; ++k) {
+        const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
+        if (len < 0 || len > 65535) { pc_set_error("pc_upload: gene %d has length %lld (limit 65535)", k, (long long)len); return PC_ERR_LIMIT; }
+        gene_len[k] = (int32_t)len; gene_off[k] = code_bytes;
+        code_bytes += (len + 15) & ~15LL;
+        maxlen = std::max(maxlen, (int)len); minlen = std::min(minlen, (int)len);
+    }
+    for (int s = 0; s < N; ++s) {
+        const int64_t k0 = g->gene_off[s], k1 = g->gene_off[s + 1];
+        if (k1 < k0 || k1 > G) { pc_set_error("pc_upload: gene_off not monotone at genome %d", s); return PC_ERR_ARG; }
+        uint64_t* row = &bitmap[(size_t)s * Wstride];
+        memcpy(row, g->bitmap + (size_t)s * W, sizeof(uint64_t) * W);
+        const size_t ent0 = ent_cnt.size();
+        int64_t tl = 0;
+        for (int64_t k = k0; k < k1;) {
+            const int32_t p = g->gene_pham[k];
+            if (p < 0 || p >= P || !((row[p >> 6] >> (p & 63)) & 1ULL) || (k > k0 && g->gene_pham[k - 1] >= p && g->gene_pham[k - 1] != p)) {
+                pc_set_error("pc_upload: genome %d gene %lld: pham id %d out of order or not in bitmap", s, (long long)k, p); return PC_ERR_ARG;
+            }
+            int64_t k2 = k; int64_t ln = 0;
+            while (k2 < k1 && g->gene_pham[k2] == p) { ln += gene_len[k2]; ++k2; }
+            ent_cnt.push_back((int32_t)(k2 - k)); ent_len.push_back((int32_t)ln); ent_gene.push_back((int32_t)k);
+            tl += ln; k = k2;
+        }
+        const size_t nent = ent_cnt.size() - ent0;
+        size_t bits = 0;
+        for (int w = 0; w < W; ++w) { rankpre[(size_t)s * W + w] = (uint32_t)(ent0 + bits); bits += (size_t)__builtin_popcountll(row[w]); }
+        if (bits != nent || (int)nent != g->nph[s] || (int)(k1 - k0) != g->ngen[s] || tl != g->tlen[s]) {
+            pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG;
+        }
+    }
+    std::vector<uint8_t> codes((size_t)std::max<int64_t>(code_bytes, 16), (uint8_t)PC_PADCODE);
+    uint8_t lut[256]; build_code_lut(lut);
+    for (int k = 0; k < G; ++k) {
+        const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
+        for (int i = 0; i < gene_len[k]; ++i) dst[i] = lut[src[i]];
+    }
+    // class order: genes grouped by the kernel variant that will align against them as columns
+    const int nvar = pc_nw_num_variants();
+    std::vector<int> gene_cls(G);
+    std::vector<int64_t> cls_count(nvar + 1, 0);
+    std::vector<int> cls_maxlb(nvar + 1, 0);
+    for (int k = 0; k < G; ++k) {
+        int v = pc_nw_choose_variant(gene_len[k]);
+        int cls = v < 0 ? nvar : v;
+        gene_cls[k] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], gene_len[k]);
+    }
+    c->cls_variant.clear(); c->cls_begin.clear(); c->cls_max_lb.clear();
+    std::vector<int64_t> cls_pos(nvar + 1, 0);
+    {
+        int64_t run = 0;
+        for (int cls = 0; cls <= nvar; ++cls) {
+            cls_pos[cls] = run;
+            if (cls_count[cls]) { c->cls_variant.push_back(cls == nvar ? -1 : cls); c->cls_begin.push_back((int32_t)run); c->cls_max_lb.push_back(cls_maxlb[cls]); }
+            run += cls_count[cls];
+        }
+        c->cls_begin.push_back((int32_t)run);
+    }
+    std::vector<int32_t> cls_order(std::max(G, 1));
+    for (int k = 0; k < G; ++k) cls_order[(size_t)cls_pos[gene_cls[k]]++] = k;
+    if ((c->cls_begin.size() + 8) * sizeof(uint32_t) + 3 * sizeof(uint64_t) > 4096) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }
+
+    // ---- device copies ---------------------------------------------------------------
+    std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
+    std::vector<int64_t> tlen(g->tlen, g->tlen + N);
+    if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
+        (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
+        (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_vec(c->b_codes, codes)) || (rc = upload_vec(c->b_nph, nph)) ||
+        (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_cls_order, cls_order)) ||
+        (rc = upload_vec(c->b_cls_idx, c->cls_begin)))
+        return rc;
+    PcDev& d = c->dev;
+    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)ent_cnt.size();
+    d.bitmap = c->b_bitmap.as<uint64_t>(); d.rankpre = c->b_rankpre.as<uint32_t>();
+    d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
+    d.gene_len = c->b_gene_len.as<int32_t>(); d.gene_off = c->b_gene_off.as<int64_t>(); d.codes = c->b_codes.as<uint8_t>();
+    d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
+    c->h_gene_len.swap(gene_len);
+    c->max_gene_len = maxlen; c->min_gene_len = minlen;
+    rc = apply_shard(c, 0, 1);
+    if (rc != PC_OK) return rc;
+    c->uploaded = true;
+    return PC_OK;
+}
+
+extern "C" int pc_set_shard(pc_ctx* c, int rank, int world) {
+    if (!c || !c->uploaded) { pc_set_error("pc_set_shard: upload first"); return PC_ERR_STATE; }
+    if (world < 1 || rank < 0 || rank >= world) { pc_set_error("pc_set_shard: rank %d of %d", rank, world); return PC_ERR_ARG; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_HIP(hipStreamSynchronize(c->stream));
+    return apply_shard(c, rank, world);
+}
+extern "C" int64_t pc_shard_pairs(const pc_ctx* c) { return c && c->uploaded ? c->shard_pairs : -1; }
+extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? c->shard_stride : -1; }
+
+// Steps 5 of the plan: launch the alignment kernels for every class that has tasks.
+static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats) {
+    const int ncls = (int)c->cls_variant.size();
+    for (int i = 0; i < ncls; ++i) {
+        const int nt = (int)(task_begin[i + 1] - task_begin[i]);
+        if (nt <= 0) continue;
+        void* scratch = nullptr; size_t sbytes = 0;
+        if (c->cls_variant[i] < 0) {
+            sbytes = pc_nw_fallback_scratch_bytes(c->cls_max_lb[i]);
+            int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc;
+            scratch = c->b_scratch.p;
+        }
+        int rc = pc_launch_nw(c->cls_variant[i], c->dev, c->b_tasks.as<PcTask>() + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
+                              c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, c->cls_max_lb[i], st);
+        if (rc != PC_OK) return rc;
+        if (stats) ++stats->n_align_launches;
+    }
+    return PC_OK;
+}
+
+static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
+    if (!c || !c->uploaded) { pc_set_error("fill: upload first"); return PC_ERR_STATE; }
+    if (metric < PC_GCS || metric > PC_PEQ) { pc_set_error("fill: metric %d", metric); return PC_ERR_ARG; }
+    if (!out) { pc_set_error("fill: out is NULL"); return PC_ERR_ARG; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    if (!st) st = c->stream;
+    const PcDev& d = c->dev;
+    const int64_t Lp = c->shard_pairs;
+    pc_stats local; memset(&local, 0, sizeof(local));
+    local.n_pairs = Lp;
+    as_distance = as_distance ? 1 : 0;
+    PC_HIP(hipEventRecord(c->ev[0], st));
+
+    if (metric == PC_GCS || metric == PC_JC) {
+        rc = pc_launch_set_popc(d, c->shard, metric, as_distance, out, condensed, st);
+        if (rc != PC_OK) return rc;
+        PC_HIP(hipEventRecord(c->ev[3], st));
+    } else if (metric == PC_POCP || metric == PC_AF) {
+        PcWalkArgs a; memset(&a, 0, sizeof(a));
+        a.out = out; a.as_distance = as_distance; a.condensed = condensed;
+        rc = pc_launch_walk(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, a, st);
+        if (rc != PC_OK) return rc;
+        PC_HIP(hipEventRecord(c->ev[3], st));
+    } else {
+        if (d.G > 0 && c->min_gene_len == 0) {
+            pc_set_error("fill: an empty translation cannot be aligned (aai/peq); the reference fails on it too"); return PC_ERR_DATA;
+        }
+        const int G = d.G;
+        const int ncls = (int)c->cls_variant.size();
+        const int64_t scan_n = std::max<int64_t>(Lp + 1, G + 1);
+        if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_col_cnt.ensure((G + 1) * 4)) ||
+            (rc = c->b_col_start.ensure((G + 1) * 4)) || (rc = c->b_col_cur.ensure((G + 1) * 4)) || (rc = c->b_cnt_q.ensure((G + 1) * 4)) ||
+            (rc = c->b_start_q.ensure((G + 1) * 4)) || (rc = c->b_ntask_q.ensure((G + 1) * 4)) || (rc = c->b_task_off_q.ensure((G + 1) * 4)) ||
+            (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(scan_n) * 4)) || (rc = c->b_totals.ensure(64)) || (rc = c->b_plan.ensure(4096)))
+            return rc;
+        // 1 COUNT
+        PC_HIP(hipMemsetAsync(c->b_na.p, 0, (Lp + 1) * 4, st));
+        PC_HIP(hipMemsetAsync(c->b_col_cnt.p, 0, (G + 1) * 4, st));
+        PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, st));
+        PcWalkArgs a; memset(&a, 0, sizeof(a));
+        a.na = c->b_na.as<uint32_t>(); a.col_cnt = c->b_col_cnt.as<uint32_t>(); a.totals = c->b_totals.as<unsigned long long>();
+        a.as_distance = as_distance; a.condensed = condensed;
+        if ((rc = pc_launch_walk(PCW_COUNT, d, c->shard, a, st))) return rc;
+        // 2 scans
+        const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
+        if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+        if ((rc = pc_launch_task_count(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_cnt_q.as<uint32_t>(), c->b_ntask_q.as<uint32_t>(), G, st))) return rc;
+        if ((rc = pc_scan_exclusive_u32(c->b_cnt_q.as<uint32_t>(), c->b_start_q.as<uint32_t>(), G + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+        if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), G + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+        // 3 read-back: task range per class + totals
+        if ((rc = pc_launch_gather_u32(c->b_task_off_q.as<uint32_t>(), c->b_cls_idx.as<int32_t>(), c->b_plan.as<uint32_t>(), ncls + 1, st))) return rc;
+        PC_HIP(hipMemcpyAsync(c->h_plan, c->b_plan.p, (ncls + 1) * 4, hipMemcpyDeviceToHost, st));
+        uint64_t* h_tot = (uint64_t*)(c->h_plan + 1000);
+        PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 24, hipMemcpyDeviceToHost, st));
+        PC_HIP(hipStreamSynchronize(st));
+        const uint64_t A = h_tot[0];
+        if (A >= 0xffffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^32-1 per-call limit; shard the job", (unsigned long long)A); return PC_ERR_LIMIT; }
+        const uint32_t ntasks = c->h_plan[ncls];
+        local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2]; local.n_tasks = ntasks;
+        if ((rc = c->b_bucket_row.ensure(std::max<uint64_t>(A, 1) * 4)) || (rc = c->b_bucket_dest.ensure(std::max<uint64_t>(A, 1) * 4)) ||
+            (rc = c->b_res.ensure(std::max<uint64_t>(A, 1) * 8)) || (rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))))
+            return rc;
+        // 4 ENUM
+        if ((rc = pc_launch_task_fill(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_start_q.as<uint32_t>(),
+                                      c->b_task_off_q.as<uint32_t>(), c->b_col_start.as<uint32_t>(), c->b_tasks.as<PcTask>(), G, st))) return rc;
+        PC_HIP(hipMemsetAsync(c->b_col_cur.p, 0, (G + 1) * 4, st));
+        a.off = c->b_off.as<uint32_t>(); a.col_start = c->b_col_start.as<uint32_t>(); a.col_cur = c->b_col_cur.as<uint32_t>();
+        a.bucket_row = c->b_bucket_row.as<int32_t>(); a.bucket_dest = c->b_bucket_dest.as<uint32_t>();
+        if ((rc = pc_launch_walk(PCW_ENUM, d, c->shard, a, st))) return rc;
+        PC_HIP(hipEventRecord(c->ev[1], st));
+        // 5 K4
+        std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
+        if ((rc = run_align_classes(c, tb.data(), st, &local))) return rc;
+        PC_HIP(hipEventRecord(c->ev[2], st));
+        // 6 REDUCE
+        a.res = c->b_res.as<uint2>(); a.out = out;
+        if ((rc = pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, d, c->shard, a, st))) return rc;
+        PC_HIP(hipEventRecord(c->ev[3], st));
+    }
+    if (stats) {
+        PC_HIP(hipEventSynchronize(c->ev[3]));
+        PC_HIP(hipEventElapsedTime(&local.ms_total, c->ev[0], c->ev[3]));
+        if (metric >= PC_AAI) {
+            PC_HIP(hipEventElapsedTime(&local.ms_plan, c->ev[0], c->ev[1]));
+            PC_HIP(hipEventElapsedTime(&local.ms_align, c->ev[1], c->ev[2]));
+            PC_HIP(hipEventElapsedTime(&local.ms_reduce, c->ev[2], c->ev[3]));
+        } else {
+            local.ms_reduce = local.ms_total;
+        }
+        *stats = local;
+    }
+    return PC_OK;
+}
+
+extern "C" int pc_fill_dev(pc_ctx* c, int metric, int as_distance, void* out_dev, void* stream, pc_stats* stats) {
+    if (c && c->uploaded && c->world != 1) { pc_set_error("pc_fill_dev: context is sharded (%d/%d); use pc_fill_shard_dev", c->rank, c->world); return PC_ERR_STATE; }
+    return fill_impl(c, metric, as_distance, (double*)out_dev, 1, (hipStream_t)stream, stats);
+}
+
+extern "C" int pc_fill(pc_ctx* c, int metric, int as_distance, double* out_condensed, pc_stats* stats) {
+    if (!c || !c->uploaded) { pc_set_error("pc_fill: upload first"); return PC_ERR_STATE; }
+    if (!out_condensed) { pc_set_error("pc_fill: out is NULL"); return PC_ERR_ARG; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    const int64_t np = (int64_t)c->dev.N * (c->dev.N - 1) / 2;
+    if ((rc = c->b_out.ensure(std::max<int64_t>(np, 1) * 8))) return rc;
+    if ((rc = pc_fill_dev(c, metric, as_distance, c->b_out.p, c->stream, stats))) return rc;
+    if (np) PC_HIP(hipMemcpyAsync(out_condensed, c->b_out.p, np * 8, hipMemcpyDeviceToHost, c->stream));
+    PC_HIP(hipStreamSynchronize(c->stream));
+    return PC_OK;
+}
+
+extern "C" int pc_fill_shard_dev(pc_ctx* c, int metric, int as_distance, void* shard_dev, void* stream, pc_stats* stats) {
+    if (!c || !c->uploaded) { pc_set_error("pc_fill_shard_dev: upload first"); return PC_ERR_STATE; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (c->shard_stride > c->shard_pairs)
+        PC_HIP(hipMemsetAsync((double*)shard_dev + c->shard_pairs, 0, (c->shard_stride - c->shard_pairs) * 8, st));
+    return fill_impl(c, metric, as_distance, (double*)shard_dev, 0, st, stats);
+}
+
+extern "C" int pc_assemble_dev(pc_ctx* c, const void* gathered_dev, int world, void* out_condensed_dev, void* stream) {
+    if (!c || !c->uploaded) { pc_set_error("pc_assemble_dev: upload first"); return PC_ERR_STATE; }
+    if (world != c->world) { pc_set_error("pc_assemble_dev: world %d != shard world %d", world, c->world); return PC_ERR_ARG; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    return pc_launch_assemble((const double*)gathered_dev, world, c->shard_stride, c->dev.N, (double*)out_condensed_dev,
+                              stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b_gene, int64_t n, int variant,
+                              int32_t* n_ident, int32_t* n_diag) {
+    if (!c || !c->uploaded) { pc_set_error("pc_align_pairs: upload first"); return PC_ERR_STATE; }
+    if (n < 0 || (n > 0 && (!a_gene || !b_gene || !n_ident || !n_diag))) { pc_set_error("pc_align_pairs: NULL argument"); return PC_ERR_ARG; }
+    if (n == 0) return PC_OK;
+    if (n >= 0x7fffffffLL) { pc_set_error("pc_align_pairs: too many pairs"); return PC_ERR_LIMIT; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    const int G = c->dev.G;
+    const int nvar = pc_nw_num_variants();
+    int forced = -2;                                   // -2: automatic
+    if (variant < 0) forced = -1;
+    else if (variant > 0) {
+        for (int v = 0; v < nvar; ++v) if (pc_nw_variant_w(v) == variant) forced = v;
+        if (forced == -2) { pc_set_error("pc_align_pairs: no systolic variant with %d columns per lane", variant); return PC_ERR_ARG; }
+    }
+    std::vector<int> cls(n);
+    std::vector<int32_t> sums(n);
+    for (int64_t k = 0; k < n; ++k) {
+        if (a_gene[k] < 0 || a_gene[k] >= G || b_gene[k] < 0 || b_gene[k] >= G) { pc_set_error("pc_align_pairs: gene index out of range at %lld", (long long)k); return PC_ERR_ARG; }
+        const int la = c->h_gene_len[a_gene[k]], lb = c->h_gene_len[b_gene[k]];
+        if (la == 0 || lb == 0) { pc_set_error("pc_align_pairs: empty translation at %lld", (long long)k); return PC_ERR_DATA; }
+        int v = forced == -2 ? pc_nw_choose_variant(lb) : forced;
+        if (v >= 0 && lb > 64 * pc_nw_variant_w(v)) { pc_set_error("pc_align_pairs: column gene of %d residues does not fit variant w=%d", lb, pc_nw_variant_w(v)); return PC_ERR_ARG; }
+        cls[k] = v < 0 ? nvar : v;
+        sums[k] = la + lb;
+    }
+    std::vector<int64_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        if (cls[x] != cls[y]) return cls[x] < cls[y];
+        if (b_gene[x] != b_gene[y]) return b_gene[x] < b_gene[y];
+        return x < y;
+    });
+    std::vector<int32_t> rows(n); std::vector<uint32_t> dest(n); std::vector<PcTask> tasks;
+    std::vector<uint32_t> cls_task_begin(nvar + 2, 0);
+    std::vector<int> cls_maxlb(nvar + 1, 0);
+    {
+        int cur_cls = -1;
+        for (int64_t i = 0; i < n;) {
+            const int64_t k = order[i];
+            while (cur_cls < cls[k]) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
+            int64_t j = i;
+            while (j < n && cls[order[j]] == cls[k] && b_gene[order[j]] == b_gene[k]) ++j;
+            for (int64_t r = i; r < j; r += PC_TASK_ROWS) {
+                PcTask t; t.gene = b_gene[k]; t.begin = (int32_t)r; t.end = (int32_t)std::min<int64_t>(j, r + PC_TASK_ROWS); t.pad = 0;
+                tasks.push_back(t);
+            }
+            cls_maxlb[cls[k]] = std::max(cls_maxlb[cls[k]], (int)c->h_gene_len[b_gene[k]]);
+            for (int64_t r = i; r < j; ++r) { rows[r] = a_gene[order[r]]; dest[r] = (uint32_t)order[r]; }
+            i = j;
+        }
+        while (cur_cls < nvar + 1) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
+    }
+    DevBuf d_sums, d_ident, d_diag;
+    hipStream_t st = c->stream;
+    auto cleanup = [&]() { d_sums.release(); d_ident.release(); d_diag.release(); };
+    if ((rc = upload_vec(c->b_bucket_row, rows)) || (rc = upload_vec(c->b_bucket_dest, dest)) || (rc = upload_vec(c->b_tasks, tasks)) ||
+        (rc = c->b_res.ensure(n * 8)) || (rc = upload_vec(d_sums, sums)) || (rc = d_ident.ensure(n * 4)) || (rc = d_diag.ensure(n * 4))) { cleanup(); return rc; }
+    for (int cl = 0; cl <= nvar; ++cl) {
+        const int nt = (int)(cls_task_begin[cl + 1] - cls_task_begin[cl]);
+        if (nt <= 0) continue;
+        void* scratch = nullptr; size_t sbytes = 0;
+        const int v = cl == nvar ? -1 : cl;
+        if (v < 0) {
+            sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[cl]);
+            if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return rc; }
+            scratch = c->b_scratch.p;
+        }
+        rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[cl], nt, c->b_bucket_row.as<int32_t>(),
+                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], st);
+        if (rc != PC_OK) { cleanup(); return rc; }
+    }
+    rc = pc_launch_unpack_res(c->b_res.as<uint2>(), d_sums.as<int32_t>(), d_ident.as<int32_t>(), d_diag.as<int32_t>(), n, st);
+    if (rc == PC_OK) {
+        hipError_t e = hipMemcpyAsync(n_ident, d_ident.p, n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(n_diag, d_diag.p, n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { pc_set_error("pc_align_pairs: %s", hipGetErrorString(e)); rc = PC_ERR_HIP; }
+    }
+    cleanup();
+    return rc;
+}
+
+// test hook for the device round(x, 6)
+extern "C" int pc_round6_probe(pc_ctx* c, const double* in, double* out, int64_t n) {
+    if (!c || n < 0) { pc_set_error("pc_round6_probe: bad argument"); return PC_ERR_ARG; }
+    if (n == 0) return PC_OK;
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    DevBuf a, b;
+    if ((rc = a.ensure(n * 8)) || (rc = b.ensure(n * 8))) { a.release(); b.release(); return rc; }
+    hipError_t e = hipMemcpyAsync(a.p, in, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { rc = pc_launch_round6_probe(a.as<double>(), b.as<double>(), n, c->stream); }
+    if (e == hipSuccess && rc == PC_OK) e = hipMemcpyAsync(out, b.p, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    a.release(); b.release();
+    if (e != hipSuccess) { pc_set_error("pc_round6_probe: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return rc;
+}

@@ -1,0 +1,90 @@
+// pc_common.h -- internal declarations shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PC_OPEN 11            // gap open   (metrics.py:160 default, parasail convention: first gap residue costs OPEN)
+#define PC_EXT 1              // gap extend
+#define PC_NEG (-(1 << 29))   // "-infinity" that survives a few subtractions without wrapping
+#define PC_PADCODE 255        // residue code of padding: never equal to a real code
+#define PC_TASK_ROWS 64       // max alignments (row sequences) per wave task
+#define PC_MAX_W 20           // widest systolic variant: 64 lanes * 20 columns = 1280 columns
+
+// Device view of the uploaded genomes (all pointers are HBM).
+struct PcDev {
+    int32_t N, Wb, Wstride, G;       // genomes, bitmap words per row, row stride in u64 (odd), genes
+    int64_t E;                        // (genome, pham) entries
+    const uint64_t* bitmap;           // [N][Wstride]
+    const uint32_t* rankpre;          // [N][Wb]   entry index of the first set bit of word w of genome g
+    const int32_t* ent_cnt;           // [E] genes of the genome in that pham
+    const int32_t* ent_len;           // [E] their summed length
+    const int32_t* ent_gene;          // [E] first gene id (genes of an entry are consecutive)
+    const int32_t* gene_len;          // [G]
+    const int64_t* gene_off;          // [G] byte offset of the gene's codes (16-byte aligned)
+    const uint8_t* codes;             // encoded residues, each gene padded to 16 B with PC_PADCODE
+    const int32_t* nph;               // [N]
+    const int32_t* ngen;              // [N]
+    const int64_t* tlen;              // [N]
+};
+
+// Static shard: the target genomes this rank owns, ascending.
+struct PcShard {
+    int32_t nown;
+    const int32_t* owned;             // [nown] target genome t
+    const int64_t* lbase;             // [nown+1] shard-local index of pair (0, owned[k]); pair (s,t) -> lbase[k] + s
+};
+
+// One wave task of the alignment kernels: column gene + a range of its bucket.
+struct PcTask { int32_t gene, begin, end, pad; };
+
+// walker modes (pc_pairs.hip)
+enum { PCW_POCP = 0, PCW_AF = 1, PCW_COUNT = 2, PCW_ENUM = 3, PCW_AAI = 4, PCW_PEQ = 5 };
+
+struct PcWalkArgs {
+    // COUNT
+    uint32_t* na;                     // [Lp] alignments per pair
+    uint32_t* col_cnt;                // [G]  alignments per column gene
+    unsigned long long* totals;       // [0] alignments [1] cells [2] residue bytes
+    // ENUM
+    const uint32_t* off;              // [Lp] exclusive scan of na
+    const uint32_t* col_start;        // [G]
+    uint32_t* col_cur;                // [G] zeroed
+    int32_t* bucket_row;              // [A] row gene
+    uint32_t* bucket_dest;            // [A] pair-major result slot
+    // AAI / PEQ
+    const uint2* res;                 // [A] (n_ident, aln_len)
+    // output (POCP, AF, AAI, PEQ)
+    double* out;
+    int as_distance;
+    int condensed;                    // 1: scipy condensed index, 0: shard-local index
+};
+
+const char* pc_hip_err(hipError_t e);
+void pc_set_error(const char* fmt, ...);
+
+#define PC_HIP(call)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess) { pc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); return PC_ERR_HIP; } \
+    } while (0)
+
+// launchers (defined next to their kernels)
+int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed, hipStream_t st);
+int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
+int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
+int64_t pc_scan_tmp_elems(int64_t n);
+int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st);
+int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const uint32_t* start_q, const uint32_t* task_off_q,
+                        uint32_t* col_start, PcTask* tasks, int G, hipStream_t st);
+int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st);
+int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st);
+int pc_launch_round6_probe(const double* in, double* out, int64_t n, hipStream_t st);
+int pc_launch_unpack_res(const uint2* res, const int32_t* la_plus_lb, int32_t* n_ident, int32_t* n_diag, int64_t n, hipStream_t st);
+
+// alignment kernels (pc_nw.hip)
+int pc_nw_num_variants();
+int pc_nw_variant_w(int v);                       // columns per lane of variant v
+int pc_nw_choose_variant(int lb);                 // -1: general fallback
+int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, hipStream_t st);
+size_t pc_nw_fallback_scratch_bytes(int max_lb);

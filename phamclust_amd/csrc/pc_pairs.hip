@@ -1,0 +1,449 @@
+// pc_pairs.hip -- genome-pair kernels: bitset-intersection popcount (gcs/jc), the
+// shared-pham walker (pocp/af, alignment planning, best-match reduce for aai/peq),
+// prefix sums, task building and shard assembly.
+//
+// Reference semantics restated here (all /root/reference/src/phamclust/):
+//   metrics.py:26-53, 56-80      gcs / jc closed forms on |B[s] & B[t]|
+//   metrics.py:83-115, 118-157   pocp / af: sums over shared phams of gene counts / lengths
+//   metrics.py:203-227           aai: anchor rule, best match (ties -> last), weighted mean
+//   metrics.py:247-253           peq = round(af,6) * round(aai,6), then round(., 6)
+//   round(x, 6)                  CPython double_round: exact half-even on the binary value
+//
+// Data layout: the genomes x phams bitmap is staged tile by tile in LDS (32 source rows
+// + 32 target rows, row stride padded to an odd number of u64 so that ds_read_b64 by 32
+// lanes of distinct rows is conflict-free); each workgroup owns a 32x32 tile of pairs.
+// These kernels are HBM/LDS-bound integer work: no MFMA.
+#include "pc_common.h"
+#include "../../include/phamclust_hip.h"
+
+#define TS 32          // tile edge (genomes)
+#define WCH 96         // bitmap words staged per chunk (P <= 6144 in one chunk)
+
+// ---------------------------------------------------------------------------------
+// round(x, 6) exactly as CPython: decimal(x) correctly rounded half-even to 6 places,
+// then the nearest double.  x in [0, 2^20).  x*1e6 = M * 15625 * 2^(e+6) exactly.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double pc_round6(double x) {
+    if (!(x > 0.0)) return 0.0;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int ex = (int)((bits >> 52) & 0x7ff);
+    unsigned long long M = bits & ((1ULL << 52) - 1);
+    int e;
+    if (ex == 0) e = -1074; else { M |= 1ULL << 52; e = ex - 1075; }
+    unsigned long long lo = M * 15625ULL, hi = __umul64hi(M, 15625ULL);   // P = hi:lo < 2^67
+    int sh = -(e + 6);
+    unsigned long long ip;
+    if (sh <= 0) {
+        ip = lo << (-sh);                                  // x >= 2^47: out of the documented domain, kept monotone
+    } else if (sh >= 68) {
+        ip = 0;                                            // x*1e6 < 0.5
+    } else if (sh < 64) {
+        ip = (sh == 0 ? lo : (lo >> sh)) | (hi << (64 - sh));
+        unsigned long long frac = lo & ((1ULL << sh) - 1), half = 1ULL << (sh - 1);
+        if (frac > half || (frac == half && (ip & 1))) ++ip;
+    } else {
+        int s2 = sh - 64;                                  // 0..3
+        ip = hi >> s2;
+        unsigned long long frac_hi = hi & ((1ULL << s2) - 1), frac_lo = lo;
+        unsigned long long half_hi = s2 ? (1ULL << (s2 - 1)) : 0, half_lo = s2 ? 0 : (1ULL << 63);
+        bool gt = frac_hi > half_hi || (frac_hi == half_hi && frac_lo > half_lo);
+        bool eq = frac_hi == half_hi && frac_lo == half_lo;
+        if (gt || (eq && (ip & 1))) ++ip;
+    }
+    return (double)ip / 1000000.0;
+}
+
+__device__ __forceinline__ double pc_finish(double sim, int as_distance) {
+    return as_distance ? pc_round6(1.0 - sim) : pc_round6(sim);
+}
+
+__global__ void k_round6_probe(const double* in, double* out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pc_round6(in[i]);
+}
+int pc_launch_round6_probe(const double* in, double* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_round6_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+
+__device__ __forceinline__ int64_t pc_out_index(const PcDev& d, const PcShard& sh, int s, int t, int k, int condensed) {
+    if (condensed) return (int64_t)s * d.N - (int64_t)s * (s + 1) / 2 + (t - s - 1);
+    return sh.lbase[k] + s;
+}
+
+// Stage one chunk of bitmap words of the tile's 32 source rows and 32 target rows.
+__device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh, int s0, int k0, int w0, int wn,
+                                              uint64_t (*rs)[WCH + 1], uint64_t (*rt)[WCH + 1]) {
+    for (int r = threadIdx.x >> 5; r < TS; r += 8) {
+        int s = s0 + r, k = k0 + r;
+        const uint64_t* ps = s < d.N ? d.bitmap + (int64_t)s * d.Wstride + w0 : nullptr;
+        const uint64_t* pt = k < sh.nown ? d.bitmap + (int64_t)sh.owned[k] * d.Wstride + w0 : nullptr;
+        for (int w = threadIdx.x & 31; w < wn; w += 32) {
+            rs[r][w] = ps ? ps[w] : 0ULL;
+            rt[r][w] = pt ? pt[w] : 0ULL;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K1+K3: gcs / jc.  shared = popcount(B[s] & B[t]); fp64 epilogue.  One workgroup per
+// 32x32 tile, 4 pairs per thread.  The fast thread index runs along the output's
+// contiguous direction (t for condensed order, s for shard-local order).
+// ---------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed) {
+    __shared__ uint64_t rs[TS][WCH + 1];
+    __shared__ uint64_t rt[TS][WCH + 1];
+    const int s0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
+    const int klast = min(k0 + TS, sh.nown) - 1;
+    if (s0 >= sh.owned[klast]) return;                       // tile entirely on/below the diagonal
+    const int f = threadIdx.x & 31, q = threadIdx.x >> 5;
+    int acc[4] = {0, 0, 0, 0};
+    for (int w0 = 0; w0 < d.Wb; w0 += WCH) {
+        const int wn = min(WCH, d.Wb - w0);
+        if (w0) __syncthreads();
+        pc_stage_tile(d, sh, s0, k0, w0, wn, rs, rt);
+        __syncthreads();
+        if (condensed) {
+            for (int w = 0; w < wn; ++w) {
+                uint64_t tw = rt[f][w];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] += __popcll(rs[q + 8 * m][w] & tw);
+            }
+        } else {
+            for (int w = 0; w < wn; ++w) {
+                uint64_t sw = rs[f][w];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] += __popcll(rt[q + 8 * m][w] & sw);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int ls = condensed ? q + 8 * m : f, lt = condensed ? f : q + 8 * m;
+        const int s = s0 + ls, k = k0 + lt;
+        if (s >= d.N || k >= sh.nown) continue;
+        const int t = sh.owned[k];
+        if (s >= t) continue;
+        const int shared = acc[m];
+        double sim = 0.0;
+        if (shared) {
+            const int tot = d.nph[s] + d.nph[t];
+            if (METRIC == PC_GCS) sim = (2.0 * (double)shared) / (double)tot;      // metrics.py:45-48
+            else sim = (double)shared / (double)(tot - shared);                     // metrics.py:75
+        }
+        out[pc_out_index(d, sh, s, t, k, condensed)] = pc_finish(sim, as_distance);
+    }
+}
+
+int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed, hipStream_t st) {
+    if (sh.nown <= 0 || d.N <= 1) return PC_OK;
+    dim3 grid((d.N + TS - 1) / TS, (sh.nown + TS - 1) / TS);
+    if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed);
+    else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_set_popc launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Shared-pham walker.  Visits the shared phams of each pair in ascending pham id;
+// entry index of pham p in genome g = rankpre[g][p>>6] + popcount(B[g][p>>6] below bit p).
+// ---------------------------------------------------------------------------------
+struct PcPairAcc {
+    uint32_t k;            // running alignment slot (ENUM / AAI / PEQ) or alignment count (COUNT)
+    int64_t cons;          // conserved gene count (POCP) or conserved length (AF / PEQ)
+    double num;            // sum of best_ident/len * len   (statistics.py:22 numerator)
+    int64_t den;           // sum of best lengths
+    int any;               // shared set non-empty
+};
+
+template <int MODE>
+__device__ __forceinline__ void pc_visit(const PcDev& d, const PcWalkArgs& a, PcPairAcc& p, uint32_t es, uint32_t et,
+                                         unsigned long long& cells, unsigned long long& rbytes) {
+    p.any = 1;
+    if (MODE == PCW_POCP) { p.cons += d.ent_cnt[es] + d.ent_cnt[et]; return; }          // metrics.py:102-103
+    if (MODE == PCW_AF) { p.cons += d.ent_len[es] + d.ent_len[et]; return; }            // metrics.py:135-147
+    const int cs = d.ent_cnt[es], ct = d.ent_cnt[et];
+    // anchor = the genome with fewer genes in the pham; tie -> source (metrics.py:208-209)
+    const bool swap = cs > ct;
+    const uint32_t ea = swap ? et : es, eb = swap ? es : et;
+    const int ca = swap ? ct : cs, cb = swap ? cs : ct;
+    const int a0 = d.ent_gene[ea], b0 = d.ent_gene[eb];
+    if (MODE == PCW_COUNT) {
+        p.k += (uint32_t)(ca * cb);
+        for (int ib = 0; ib < cb; ++ib) atomicAdd(&a.col_cnt[b0 + ib], (uint32_t)ca);
+        const unsigned long long la = (unsigned long long)d.ent_len[ea], lb = (unsigned long long)d.ent_len[eb];
+        cells += la * lb;
+        rbytes += la * cb + lb * ca;
+    } else if (MODE == PCW_ENUM) {
+        for (int ia = 0; ia < ca; ++ia)
+            for (int ib = 0; ib < cb; ++ib) {
+                const int b = b0 + ib;
+                const uint32_t pos = a.col_start[b] + atomicAdd(&a.col_cur[b], 1u);
+                a.bucket_row[pos] = a0 + ia;
+                a.bucket_dest[pos] = p.k++;
+            }
+    } else {                                                                              // AAI / PEQ
+        if (MODE == PCW_PEQ) p.cons += d.ent_len[es] + d.ent_len[et];
+        for (int ia = 0; ia < ca; ++ia) {
+            double best = -1.0; uint32_t best_len = 0;
+            for (int ib = 0; ib < cb; ++ib) {
+                const uint2 r = a.res[p.k++];
+                const double x = (double)r.x / (double)r.y;                               // metrics.py:221
+                if (x >= best) { best = x; best_len = r.y; }                              // sorted(...)[-1] (metrics.py:223)
+            }
+            p.num = p.num + best * (double)best_len;                                      // statistics.py:22
+            p.den += best_len;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a) {
+    __shared__ uint64_t rs[TS][WCH + 1];
+    __shared__ uint64_t rt[TS][WCH + 1];
+    __shared__ unsigned long long red[3];
+    const int s0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
+    const int klast = min(k0 + TS, sh.nown) - 1;
+    if (s0 >= sh.owned[klast]) return;
+    const int f = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int cond = a.condensed;
+    PcPairAcc acc[4];
+    int ss[4], kk[4], tt[4]; bool ok[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int ls = cond ? q + 8 * m : f, lt = cond ? f : q + 8 * m;
+        ss[m] = s0 + ls; kk[m] = k0 + lt;
+        ok[m] = ss[m] < d.N && kk[m] < sh.nown;
+        tt[m] = ok[m] ? sh.owned[kk[m]] : 0;
+        ok[m] = ok[m] && ss[m] < tt[m];
+        acc[m].k = 0; acc[m].cons = 0; acc[m].num = 0.0; acc[m].den = 0; acc[m].any = 0;
+        if (ok[m] && (MODE == PCW_ENUM || MODE == PCW_AAI || MODE == PCW_PEQ)) acc[m].k = a.off[sh.lbase[kk[m]] + ss[m]];
+    }
+    unsigned long long cells = 0, rbytes = 0;
+    if (MODE == PCW_COUNT) { if (threadIdx.x < 3) red[threadIdx.x] = 0; }
+
+    for (int w0 = 0; w0 < d.Wb; w0 += WCH) {
+        const int wn = min(WCH, d.Wb - w0);
+        if (w0) __syncthreads();
+        pc_stage_tile(d, sh, s0, k0, w0, wn, rs, rt);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (!ok[m]) continue;
+            const int ls = ss[m] - s0, lt = kk[m] - k0;
+            const uint32_t* rps = d.rankpre + (int64_t)ss[m] * d.Wb + w0;
+            const uint32_t* rpt = d.rankpre + (int64_t)tt[m] * d.Wb + w0;
+            for (int w = 0; w < wn; ++w) {
+                const uint64_t sw = rs[ls][w], tw = rt[lt][w];
+                uint64_t x = sw & tw;
+                if (!x) continue;
+                const uint32_t bs = rps[w], bt = rpt[w];
+                while (x) {
+                    const int b = __ffsll((long long)x) - 1;
+                    x &= x - 1;
+                    const uint64_t below = (1ULL << b) - 1;
+                    pc_visit<MODE>(d, a, acc[m], bs + __popcll(sw & below), bt + __popcll(tw & below), cells, rbytes);
+                }
+            }
+        }
+    }
+
+    if (MODE == PCW_COUNT) {
+        unsigned long long nal = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (ok[m]) { a.na[sh.lbase[kk[m]] + ss[m]] = acc[m].k; nal += acc[m].k; }
+        for (int o = 32; o > 0; o >>= 1) {
+            nal += __shfl_down(nal, o); cells += __shfl_down(cells, o); rbytes += __shfl_down(rbytes, o);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], nal); atomicAdd(&red[1], cells); atomicAdd(&red[2], rbytes); }
+        __syncthreads();
+        if (threadIdx.x < 3 && red[threadIdx.x]) atomicAdd(&a.totals[threadIdx.x], red[threadIdx.x]);
+        return;
+    }
+    if (MODE == PCW_ENUM) return;
+
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (!ok[m]) continue;
+        const int s = ss[m], t = tt[m];
+        double v;
+        if (MODE == PCW_POCP) {
+            const double sim = acc[m].any ? (double)acc[m].cons / (double)(d.ngen[s] + d.ngen[t]) : 0.0;   // metrics.py:104-110
+            v = pc_finish(sim, a.as_distance);
+        } else if (MODE == PCW_AF) {
+            const double sim = acc[m].any ? (double)acc[m].cons / (double)(d.tlen[s] + d.tlen[t]) : 0.0;   // metrics.py:149-152
+            v = pc_finish(sim, a.as_distance);
+        } else {
+            const double aai = acc[m].any ? acc[m].num / (double)acc[m].den : 0.0;                         // metrics.py:227
+            if (MODE == PCW_AAI) v = pc_finish(aai, a.as_distance);
+            else {
+                const double af = acc[m].any ? (double)acc[m].cons / (double)(d.tlen[s] + d.tlen[t]) : 0.0;
+                v = pc_finish(pc_round6(af) * pc_round6(aai), a.as_distance);                              // metrics.py:247-253
+            }
+        }
+        a.out[pc_out_index(d, sh, s, t, kk[m], cond)] = v;
+    }
+}
+
+int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st) {
+    if (sh.nown <= 0 || d.N <= 1) return PC_OK;
+    dim3 grid((d.N + TS - 1) / TS, (sh.nown + TS - 1) / TS), block(256);
+    switch (mode) {
+    case PCW_POCP: hipLaunchKernelGGL(k_walk<PCW_POCP>, grid, block, 0, st, d, sh, a); break;
+    case PCW_AF: hipLaunchKernelGGL(k_walk<PCW_AF>, grid, block, 0, st, d, sh, a); break;
+    case PCW_COUNT: hipLaunchKernelGGL(k_walk<PCW_COUNT>, grid, block, 0, st, d, sh, a); break;
+    case PCW_ENUM: hipLaunchKernelGGL(k_walk<PCW_ENUM>, grid, block, 0, st, d, sh, a); break;
+    case PCW_AAI: hipLaunchKernelGGL(k_walk<PCW_AAI>, grid, block, 0, st, d, sh, a); break;
+    case PCW_PEQ: hipLaunchKernelGGL(k_walk<PCW_PEQ>, grid, block, 0, st, d, sh, a); break;
+    default: pc_set_error("pc_launch_walk: bad mode %d", mode); return PC_ERR_ARG;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_walk launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Exclusive prefix sum of u32 (n elements).  2048 elements per workgroup, block sums
+// scanned recursively.  Callers that need the total pass n+1 elements with in[n] = 0.
+// ---------------------------------------------------------------------------------
+#define SCAN_PER_BLOCK 2048
+
+__global__ __launch_bounds__(256) void k_scan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                     uint32_t* __restrict__ sums, int64_t n) {
+    __shared__ uint32_t wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_PER_BLOCK + (int64_t)threadIdx.x * 8;
+    uint32_t v[8], tot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; tot += v[i]; }
+    // wave inclusive scan of the per-thread totals
+    uint32_t incl = tot;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int i = 0; i < wv; ++i) woff += wsum[i];
+    uint32_t run = woff + incl - tot;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == 255 && sums) sums[blockIdx.x] = woff + incl;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ sums, int64_t n) {
+    const uint32_t add = sums[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_PER_BLOCK + (int64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (base + i < n) out[base + i] += add;
+}
+
+int64_t pc_scan_tmp_elems(int64_t n) {
+    int64_t tot = 0;
+    while (n > SCAN_PER_BLOCK) { n = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK; tot += n; }
+    return tot + 1;
+}
+
+int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st) {
+    if (n <= 0) return PC_OK;
+    const int64_t nb = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    if (nb == 1) {
+        hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(256), 0, st, in, out, (uint32_t*)nullptr, n);
+    } else {
+        if (tmp_elems < nb) { pc_set_error("scan: temp too small"); return PC_ERR_ARG; }
+        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, st, in, out, tmp, n);
+        int rc = pc_scan_exclusive_u32(tmp, tmp, nb, tmp + nb, tmp_elems - nb, st);
+        if (rc != PC_OK) return rc;
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(256), 0, st, out, tmp, n);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("scan launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Wave-task building.  Genes are visited in class order (grouped by kernel variant).
+// ---------------------------------------------------------------------------------
+__global__ void k_task_count(const int32_t* __restrict__ cls_order, const uint32_t* __restrict__ col_cnt,
+                             uint32_t* __restrict__ cnt_q, uint32_t* __restrict__ ntask_q, int G) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > G) return;
+    uint32_t n = q < G ? col_cnt[cls_order[q]] : 0u;
+    cnt_q[q] = n;
+    ntask_q[q] = (n + PC_TASK_ROWS - 1) / PC_TASK_ROWS;
+}
+
+__global__ void k_task_fill(const int32_t* __restrict__ cls_order, const uint32_t* __restrict__ col_cnt,
+                            const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ task_off_q,
+                            uint32_t* __restrict__ col_start, PcTask* __restrict__ tasks, int G) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= G) return;
+    const int g = cls_order[q];
+    const uint32_t n = col_cnt[g], st = start_q[q];
+    col_start[g] = st;
+    uint32_t to = task_off_q[q];
+    for (uint32_t r = 0; r < n; r += PC_TASK_ROWS) {
+        PcTask t; t.gene = g; t.begin = (int32_t)(st + r); t.end = (int32_t)(st + min(n, r + PC_TASK_ROWS)); t.pad = 0;
+        tasks[to++] = t;
+    }
+}
+
+int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st) {
+    hipLaunchKernelGGL(k_task_count, dim3((G + 1 + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, cnt_q, ntask_q, G);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const uint32_t* start_q, const uint32_t* task_off_q,
+                        uint32_t* col_start, PcTask* tasks, int G, hipStream_t st) {
+    if (G <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_task_fill, dim3((G + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, start_q, task_off_q, col_start, tasks, G);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+
+__global__ void k_gather_u32(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, uint32_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_u32, dim3((n + 63) / 64), dim3(64), 0, st, src, idx, dst, n);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------
+// Shard assembly on the root: gathered[r][lbase_r(k) + s] -> condensed(s, t).
+// The boustrophedon deal has closed forms: round j = t / world, rank r = pos or
+// world-1-pos, and lbase_r(k) = world*k(k-1)/2 + r*ceil(k/2) + (world-1-r)*floor(k/2).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gathered, int world, int64_t stride, int N,
+                                                   double* __restrict__ out) {
+    const int s = blockIdx.y;
+    const int t = s + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const int j = t / world, pos = t % world;
+    const int r = (j & 1) ? world - 1 - pos : pos;
+    const int64_t k = j;
+    const int64_t lbase = (int64_t)world * (k * (k - 1) / 2) + (int64_t)r * ((k + 1) / 2) + (int64_t)(world - 1 - r) * (k / 2);
+    out[(int64_t)s * N - (int64_t)s * (s + 1) / 2 + (t - s - 1)] = gathered[(int64_t)r * stride + lbase + s];
+}
+int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st) {
+    if (N <= 1) return PC_OK;
+    dim3 grid((N + 255) / 256, N - 1);
+    hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, st, gathered, world, stride, N, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_assemble launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// (n_ident, aln_len) -> (n_ident, n_diag) for the pc_align_pairs test hook
+__global__ void k_unpack_res(const uint2* __restrict__ res, const int32_t* __restrict__ la_plus_lb,
+                             int32_t* __restrict__ n_ident, int32_t* __restrict__ n_diag, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    n_ident[i] = (int32_t)res[i].x;
+    n_diag[i] = la_plus_lb[i] - (int32_t)res[i].y;
+}
+int pc_launch_unpack_res(const uint2* res, const int32_t* la_plus_lb, int32_t* n_ident, int32_t* n_diag, int64_t n, hipStream_t st) {
+    if (n <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_unpack_res, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, res, la_plus_lb, n_ident, n_diag, n);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}

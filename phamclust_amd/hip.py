@@ -1,0 +1,188 @@
+"""ctypes binding of ``libphamclust_hip.so`` (C-ABI: ``include/phamclust_hip.h``).
+
+This is the only way the package computes anything: there is no CPU fallback.  If the
+library is missing or a call fails, the error is raised, never papered over.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libphamclust_hip.so")
+METRIC_IDS = {"gcs": 0, "jc": 1, "pocp": 2, "af": 3, "aai": 4, "peq": 5}
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP library is missing, or one of its entry points returned an error."""
+
+
+class PcPacked(ctypes.Structure):
+    _fields_ = [("n_genomes", ctypes.c_int32), ("n_phams", ctypes.c_int32),
+                ("words_per_row", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("bitmap", _u64p), ("nph", _i32p), ("ngen", _i32p), ("tlen", _i64p),
+                ("gene_off", _i64p), ("gene_pham", _i32p), ("seq_off", _i64p), ("residues", _u8p)]
+
+
+class PcStats(ctypes.Structure):
+    _fields_ = [("n_pairs", ctypes.c_int64), ("n_alignments", ctypes.c_int64), ("n_cells", ctypes.c_int64),
+                ("n_tasks", ctypes.c_int64), ("n_residue_bytes", ctypes.c_int64),
+                ("n_align_launches", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("ms_total", ctypes.c_float), ("ms_plan", ctypes.c_float), ("ms_align", ctypes.c_float),
+                ("ms_reduce", ctypes.c_float)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard",
+           "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
+           "pc_align_pairs", "pc_round6_probe"]
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises :class:`HipLibraryError` when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(f"{LIB_PATH} not found: build it with `python -m phamclust_amd.build` "
+                              f"(there is no CPU fallback)")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from None
+    vp = ctypes.c_void_p
+    L.pc_version.restype = ctypes.c_int
+    L.pc_last_error.restype = ctypes.c_char_p
+    L.pc_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    L.pc_ctx_destroy.argtypes = [vp]
+    L.pc_ctx_destroy.restype = None
+    L.pc_upload.argtypes = [vp, ctypes.POINTER(PcPacked)]
+    L.pc_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.pc_shard_pairs.argtypes = [vp]
+    L.pc_shard_pairs.restype = ctypes.c_int64
+    L.pc_shard_stride.argtypes = [vp]
+    L.pc_shard_stride.restype = ctypes.c_int64
+    L.pc_fill.argtypes = [vp, ctypes.c_int, ctypes.c_int, _f64p, ctypes.POINTER(PcStats)]
+    L.pc_fill_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
+    L.pc_fill_shard_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
+    L.pc_assemble_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+    L.pc_align_pairs.argtypes = [vp, _i32p, _i32p, ctypes.c_int64, ctypes.c_int, _i32p, _i32p]
+    L.pc_round6_probe.argtypes = [vp, _f64p, _f64p, ctypes.c_int64]
+    _lib = L
+    return L
+
+
+def _ptr(arr, typ):
+    return arr.ctypes.data_as(typ)
+
+
+class Context:
+    """One GPU.  ``upload`` once, then ``fill`` any of the six metrics."""
+
+    def __init__(self, device_id=0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        self._packed = None
+        self._check(self._lib.pc_ctx_create(ctypes.byref(self._h), int(device_id)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HipLibraryError(f"libphamclust_hip: status {rc}: {self._lib.pc_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pc_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ------------------------------------------------------------------
+    def upload(self, packed):
+        packed.validate()
+        s = PcPacked(packed.n_genomes, packed.n_phams, packed.words_per_row, 0,
+                     _ptr(packed.bitmap, _u64p), _ptr(packed.nph, _i32p), _ptr(packed.ngen, _i32p),
+                     _ptr(packed.tlen, _i64p), _ptr(packed.gene_off, _i64p), _ptr(packed.gene_pham, _i32p),
+                     _ptr(packed.seq_off, _i64p), _ptr(packed.residues, _u8p))
+        self._check(self._lib.pc_upload(self._h, ctypes.byref(s)))
+        self._packed = packed
+        return self
+
+    @property
+    def n_genomes(self):
+        return self._packed.n_genomes
+
+    @property
+    def n_pairs(self):
+        return self._packed.n_pairs
+
+    def set_shard(self, rank, world):
+        self._check(self._lib.pc_set_shard(self._h, int(rank), int(world)))
+
+    def shard_pairs(self):
+        return int(self._lib.pc_shard_pairs(self._h))
+
+    def shard_stride(self):
+        return int(self._lib.pc_shard_stride(self._h))
+
+    # -- fills -------------------------------------------------------------------
+    def fill(self, metric, as_distance=True, want_stats=False):
+        """Whole matrix -> host condensed f64 vector (scipy order)."""
+        out = np.empty(max(self.n_pairs, 0), dtype=np.float64)
+        stats = PcStats()
+        buf = out if out.size else np.zeros(1)
+        self._check(self._lib.pc_fill(self._h, METRIC_IDS[metric], int(bool(as_distance)), _ptr(buf, _f64p),
+                                      ctypes.byref(stats)))
+        return (out, stats.as_dict()) if want_stats else out
+
+    def fill_dev(self, metric, as_distance, out_ptr, stream=None, want_stats=True):
+        stats = PcStats()
+        self._check(self._lib.pc_fill_dev(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.c_void_p(out_ptr),
+                                          ctypes.c_void_p(stream or 0), ctypes.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
+
+    def fill_shard_dev(self, metric, as_distance, shard_ptr, stream=None, want_stats=True):
+        stats = PcStats()
+        self._check(self._lib.pc_fill_shard_dev(self._h, METRIC_IDS[metric], int(bool(as_distance)),
+                                                ctypes.c_void_p(shard_ptr), ctypes.c_void_p(stream or 0),
+                                                ctypes.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
+
+    def assemble_dev(self, gathered_ptr, world, out_ptr, stream=None):
+        self._check(self._lib.pc_assemble_dev(self._h, ctypes.c_void_p(gathered_ptr), int(world),
+                                              ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream or 0)))
+
+    # -- test hooks --------------------------------------------------------------
+    def align_pairs(self, a_gene, b_gene, variant=0):
+        a = np.ascontiguousarray(a_gene, dtype=np.int32)
+        b = np.ascontiguousarray(b_gene, dtype=np.int32)
+        n = a.shape[0]
+        ident, diag = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._check(self._lib.pc_align_pairs(self._h, _ptr(a, _i32p), _ptr(b, _i32p), n, int(variant),
+                                             _ptr(ident, _i32p), _ptr(diag, _i32p)))
+        return ident, diag
+
+    def round6(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        out = np.empty_like(v)
+        self._check(self._lib.pc_round6_probe(self._h, _ptr(v, _f64p), _ptr(out, _f64p), v.shape[0]))
+        return out

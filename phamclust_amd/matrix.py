@@ -1,0 +1,420 @@
+"""``SymMatrix`` and ``matrix_de_novo``: the reference's matrix.py surface over ndarray storage.
+
+``matrix_de_novo(genomes, func, cpus, as_distance=True)`` is the drop-in boundary
+(reference matrix.py:432-497, called from scripts/phamclust.py:258).  When ``func`` is one
+of the six ``METRICS`` callables the whole N x N fill runs on the GPU through
+``libphamclust_hip.so`` (one upload, one ``pc_fill``); any other callable takes the generic
+per-pair loop with the reference's semantics.  There is no CPU fallback for the six
+metrics: a missing library or a failing call raises.
+
+``SymMatrix`` keeps the reference's method surface (matrix.py:33-405) but stores a dense
+float64 array (NaN = unset) plus a name -> slot map instead of a dict of dicts, so the
+downstream clustering step gets its ndarray without N^2 Python calls.  Behaviour kept on
+purpose: weights are rounded to 6 places and range-checked on write (matrix.py:316-323),
+``__iter__`` yields the upper half incl. the diagonal in current node order
+(matrix.py:368-379), ``medoid`` counts the diagonal twice and breaks ties by node order
+(matrix.py:80-104), ``lock()`` makes writes fail (matrix.py:308-309).
+"""
+
+import logging
+import os
+
+import numpy as np
+from scipy.cluster.hierarchy import dendrogram, linkage
+from scipy.spatial.distance import squareform
+
+from phamclust_amd.statistics import average, skewness, standard_deviation
+
+
+class SymMatrix:
+    def __init__(self, nodes, is_distance=False):
+        self._nodes = nodes
+        self._slot = {name: k for k, name in enumerate(nodes)}
+        n = len(nodes)
+        self._data = np.full((n, n), np.nan, dtype=np.float64)
+        self._is_distance = is_distance
+        self._locked = False
+
+    # -- bulk constructors (new; used by the GPU fill) -----------------------------
+    @classmethod
+    def from_condensed(cls, nodes, condensed, is_distance=True):
+        """Build from a scipy-condensed vector whose values are already rounded to 6 places;
+        the diagonal is preset to ``1.0 - is_distance`` as matrix_de_novo does (matrix.py:467-468)."""
+        self = cls(list(nodes), is_distance=is_distance)
+        n = len(self._nodes)
+        condensed = np.asarray(condensed, dtype=np.float64)
+        if condensed.shape != (n * (n - 1) // 2,):
+            raise ValueError(f"need {n * (n - 1) // 2} condensed values but got {condensed.shape}")
+        if condensed.size and not (np.nanmin(condensed) >= 0.0 and np.nanmax(condensed) <= 1.0):
+            raise ValueError("weight not in [0.0, 1.0]")
+        if n > 1:
+            iu = np.triu_indices(n, k=1)
+            self._data[iu] = condensed
+            self._data[(iu[1], iu[0])] = condensed
+        np.fill_diagonal(self._data, 0.0 if is_distance else 1.0)
+        return self
+
+    # -- properties ------------------------------------------------------------------
+    @property
+    def is_distance(self):
+        return self._is_distance
+
+    @property
+    def nodes(self):
+        return self._nodes[:]
+
+    def _order(self):
+        return np.fromiter((self._slot[name] for name in self._nodes), dtype=np.int64, count=len(self._nodes))
+
+    def _ordered(self):
+        order = self._order()
+        return self._data[np.ix_(order, order)]
+
+    @property
+    def diameter(self):
+        if not self.is_distance:
+            raise ValueError("cannot compute diameter for similarity matrix")
+        n = len(self)
+        if n < 2:
+            return 0.0
+        off = self._ordered()[np.triu_indices(n, k=1)]
+        top = np.nanmax(off) if off.size else 0.0
+        return round(float(max(top, 0.0)), 6)
+
+    def _central(self):
+        """Per node, the mean of its N+1 incident weights (diagonal twice), summed in the
+        reference's order (matrix.py:84-97) so that ties fall the same way."""
+        n = len(self)
+        m = self._ordered()
+        wide = np.empty((n, n + 1), dtype=np.float64)
+        rows = np.arange(n)
+        for k in range(n):                       # row k: w(0..k, k), w(k,k) again, w(k, k+1..)
+            wide[k, :k + 1] = m[k, :k + 1]
+            wide[k, k + 1] = m[k, k]
+            wide[k, k + 2:] = m[k, k + 1:]
+        totals = np.add.accumulate(wide, axis=1)[rows, -1]
+        return [(name, float(total) / (n + 1)) for name, total in zip(self._nodes, totals)]
+
+    @property
+    def medoid(self):
+        scored = sorted(self._central(), key=lambda item: item[1])
+        return scored[0] if self.is_distance else scored[-1]
+
+    @property
+    def anti_medoid(self):
+        scored = sorted(self._central(), key=lambda item: item[1])
+        return scored[-1] if self.is_distance else scored[0]
+
+    @property
+    def statistics(self):
+        if len(self) == 1:
+            node = self._nodes[0]
+            return self.get_weight(node, node), 0.0, 0.0
+        n = len(self)
+        edges = self._ordered()[np.triu_indices(n, k=1)].tolist()
+        mean = average(edges)
+        std_dev = standard_deviation(edges, mean)
+        skew = 0.0 if std_dev == 0.0 else skewness(edges, mean)
+        return mean, std_dev, skew
+
+    # -- structure -------------------------------------------------------------------
+    def extract_submatrix(self, nodes):
+        for name in nodes:
+            if name not in self:
+                raise KeyError(f"node '{name}' not in matrix")
+        sub = SymMatrix(nodes, self.is_distance)
+        idx = np.fromiter((self._slot[name] for name in nodes), dtype=np.int64, count=len(nodes))
+        sub._data = self._data[np.ix_(idx, idx)].copy()
+        return sub
+
+    def append_node(self, source, data):
+        if source in self:
+            raise KeyError(f"node '{source}' is already in this matrix")
+        if source not in data:
+            raise KeyError(f"incoming data lacks an self-edge for '{source}'")
+        if self.is_distance and data[source] != 0.0:
+            raise ValueError(f"nonsense value {data[source]} for self-edge on distance matrix")
+        if not self.is_distance and data[source] != 1.0:
+            raise ValueError(f"nonsense value {data[source]} for self-edge on similarity matrix")
+        missed = set(self._slot) - data.keys()
+        if missed:
+            raise KeyError(f"missing edge(s) for {source} vs: {missed}")
+        extra = set(data.keys()) - {source} - set(self._slot)
+        if extra:
+            raise KeyError(f"specified edges for nodes not found in matrix: {extra}")
+        n = self._data.shape[0]
+        grown = np.full((n + 1, n + 1), np.nan, dtype=np.float64)
+        grown[:n, :n] = self._data
+        self._data = grown
+        self._slot[source] = n
+        self._nodes.append(source)
+        for target in self._nodes:
+            self.set_weight(source, target, data[target])
+
+    def get_weight(self, source, target):
+        if source not in self:
+            raise KeyError(f"node '{source}' not in matrix")
+        if target not in self:
+            raise KeyError(f"node '{target}' not in matrix")
+        value = self._data[self._slot[source], self._slot[target]]
+        return None if value != value else float(value)
+
+    def set_weight(self, source, target, weight):
+        if self._locked:
+            raise AttributeError("matrix is marked as read-only")
+        if source not in self:
+            raise KeyError(f"node '{source}' not in matrix")
+        if target not in self:
+            raise KeyError(f"node '{target}' not in matrix")
+        if not 0 <= weight <= 1:
+            raise ValueError(f"weight {weight} not in [0.0, 1.0]")
+        i, j = self._slot[source], self._slot[target]
+        self._data[i, j] = self._data[j, i] = round(weight, 6)
+
+    def invert(self):
+        """distance <-> similarity in place: every stored w becomes round(1 - w, 6)
+        (matrix.py:236-247).  Stored values are 6-place decimals, so numpy's rounding and
+        Python's agree here."""
+        if self._locked:
+            raise AttributeError("matrix is marked as read-only")
+        self._data = np.round(1.0 - self._data, 6)
+        self._is_distance = not self.is_distance
+        return self
+
+    def reorder(self, nodes=None):
+        if not nodes:
+            nodes = [self._nodes[x] for x in _get_tree_order(self)]
+        if len(nodes) != len(self):
+            raise ValueError(f"need {len(self)} nodes but got {len(nodes)}")
+        for node in nodes:
+            if node not in self:
+                raise KeyError(f"node '{node}' not in matrix")
+        self._nodes = nodes
+
+    def nearest_neighbors(self, source, threshold):
+        is_distance = self.is_distance
+        neighbors = []
+        for target in self._nodes:
+            if source == target:
+                continue
+            weight = self.get_weight(source, target)
+            if (is_distance and weight <= threshold) or (not is_distance and weight >= threshold):
+                neighbors.append(target)
+        return sorted(neighbors, reverse=not is_distance, key=lambda x: self.get_weight(source, x))
+
+    def lock(self):
+        self._locked = True
+
+    def unlock(self):
+        self._locked = False
+
+    def is_locked(self):
+        return self._locked
+
+    def to_ndarray(self, condensed=False):
+        full = self._ordered()
+        if condensed:
+            return squareform(full, force="tovector")
+        return full
+
+    # -- container protocol ------------------------------------------------------------
+    def __contains__(self, item):
+        if not isinstance(item, str):
+            raise TypeError(f"type(item) should be 'str', not '{type(item)}'")
+        return item in self._slot
+
+    def __getitem__(self, item):
+        """Row of ``item`` as the reference stores it: only targets that do not sort before
+        ``item`` as strings (matrix.py:231-232, 320-321)."""
+        if item not in self:
+            raise KeyError(f"node '{item}' not in matrix")
+        row = self._data[self._slot[item]]
+        return {name: float(row[k]) for name, k in self._slot.items() if not name < item and row[k] == row[k]}
+
+    def __iter__(self):
+        m = self._ordered()
+        for i, source in enumerate(self._nodes):
+            row = m[i]
+            for j in range(i, len(self._nodes)):
+                value = row[j]
+                yield source, self._nodes[j], (None if value != value else float(value))
+
+    def iterrows(self):
+        m = self._ordered()
+        for i, source in enumerate(self._nodes):
+            yield source, [None if v != v else v for v in m[i].tolist()]
+
+    def __len__(self):
+        return len(self._nodes)
+
+    def __lt__(self, other):
+        if not isinstance(other, SymMatrix):
+            raise TypeError(f"cannot compare SymMatrix to {type(other)}")
+        return len(self) < len(other)
+
+    def __str__(self):
+        lines = [f"{len(self)}\n"]
+        for source, row in self.iterrows():
+            lines.append(f"{source:<24}\t" + "\t".join([f"{x:.6f}" for x in row]) + "\n")
+        return "".join(lines)
+
+
+# ---------------------------------------------------------------------------------------
+# matrix_de_novo
+# ---------------------------------------------------------------------------------------
+def _outside_in_index_iterator(num_indices):
+    """Indices from both ends toward the middle: 5 -> 0, 4, 1, 3, 2 (matrix.py:409-423)."""
+    lo, hi = 0, num_indices - 1
+    while lo < hi:
+        yield lo
+        yield hi
+        lo, hi = lo + 1, hi - 1
+    if lo == hi:
+        yield lo
+
+
+def calculate_adjacency(source, target, func, distance=True):
+    return source.name, target.name, func(source, target, as_distance=distance)
+
+
+_CONTEXTS = {}
+
+
+def default_device():
+    return int(os.environ.get("PHAMCLUST_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def get_context(device_id=None):
+    """One cached HIP context per device for the life of the process."""
+    from phamclust_amd import hip
+    device_id = default_device() if device_id is None else device_id
+    if device_id not in _CONTEXTS:
+        _CONTEXTS[device_id] = hip.Context(device_id)
+    return _CONTEXTS[device_id]
+
+
+def _metric_name(func):
+    from phamclust_amd import metrics
+    return metrics.ACCELERATED.get(func)
+
+
+def matrix_de_novo(genomes, func, cpus, as_distance=True):
+    """Fill an N x N ``SymMatrix`` with ``func`` over every genome pair (matrix.py:432-497).
+
+    ``cpus`` is accepted for signature compatibility; the six METRICS run on the GPU.
+    """
+    if len(genomes) == 0:
+        raise ValueError("need at least 1 genome to construct matrix de novo")
+    names = [g.name for g in genomes]
+    metric = _metric_name(func)
+    if metric is not None:
+        from phamclust_amd.pack import pack_genomes
+        ctx = get_context()
+        ctx.upload(pack_genomes(genomes))
+        condensed, stats = ctx.fill(metric, as_distance=as_distance, want_stats=True)
+        logging.debug(f"{len(genomes)} genomes -> {condensed.size} edges on device in {stats['ms_total']:.3f} ms")
+        return SymMatrix.from_condensed(names, condensed, is_distance=as_distance)
+
+    # any other callable: the reference's per-pair semantics, in its batch order
+    matrix = SymMatrix(nodes=names, is_distance=as_distance)
+    for genome in genomes:
+        matrix.set_weight(genome.name, genome.name, 1.0 - as_distance)
+    for i in _outside_in_index_iterator(len(genomes)):
+        source = genomes[i]
+        for target in genomes[i + 1:]:
+            s, t, w = calculate_adjacency(source, target, func, as_distance)
+            matrix.set_weight(s, t, w)
+    return matrix
+
+
+# ---------------------------------------------------------------------------------------
+# TSV I/O: adjacency, squareform, lower triangle (matrix.py:500-670); "%.6f" everywhere
+# ---------------------------------------------------------------------------------------
+def read_adjacency(filepath):
+    with open(filepath, "r") as handle:
+        for line in handle:
+            fields = line.rstrip().split("\t")
+            yield fields[0], fields[1], float(fields[2])
+
+
+def _diagonal_kind(diagonal, count):
+    if len(diagonal) > 1:
+        raise ValueError("values on matrix diagonal should be identical")
+    total = sum(diagonal)
+    if total == 0.0:
+        return True
+    if total == count:
+        return False
+    raise ValueError("values on matrix diagonal can only be 0.0 or 1.0")
+
+
+def matrix_from_adjacency(filepath):
+    names, diagonal = dict(), set()
+    for source, target, weight in read_adjacency(filepath):
+        if source == target:
+            diagonal.add(weight)
+        if target in names:
+            break
+        names[target] = None
+    matrix = SymMatrix(list(names), is_distance=_diagonal_kind(diagonal, 1.0))
+    for source, target, weight in read_adjacency(filepath):
+        matrix.set_weight(source, target, weight)
+    return matrix
+
+
+def matrix_to_adjacency(matrix, filepath, skip_zero=False):
+    with open(filepath, "w") as handle:
+        for source, target, weight in matrix:
+            if skip_zero and not weight:
+                continue
+            handle.write(f"{source}\t{target}\t{weight:.6f}\n")
+    return filepath
+
+
+def read_squareform(filepath):
+    with open(filepath, "r") as handle:
+        next(handle)
+        for line in handle:
+            fields = line.rstrip().split("\t")
+            yield fields[0], [float(x) for x in fields[1:]]
+
+
+def matrix_from_squareform(filepath):
+    names, rows, diagonal = [], [], set()
+    for i, (target, row) in enumerate(read_squareform(filepath)):
+        names.append(target)
+        rows.append(row)
+        diagonal.add(row[i])
+    matrix = SymMatrix(names, is_distance=_diagonal_kind(diagonal, len(diagonal)))
+    n = len(names)
+    data = matrix._data
+    for i, row in enumerate(rows):
+        values = np.asarray(row[:i + 1], dtype=np.float64)
+        if values.size and not (values.min() >= 0.0 and values.max() <= 1.0):
+            raise ValueError(f"weight not in [0.0, 1.0] on row {i}")
+        values = np.round(values, 6)
+        data[i, :i + 1] = values
+        data[:i + 1, i] = values
+    assert data.shape == (n, n)
+    return matrix
+
+
+def matrix_to_squareform(matrix, filepath, lower_triangle=False):
+    with open(filepath, "w") as handle:
+        header = f"{len(matrix)}"
+        if not lower_triangle:
+            header += "\t" + "\t".join(matrix.nodes)
+        handle.write(f"{header}\n")
+        for i, (source, row) in enumerate(matrix.iterrows()):
+            cells = row[:i + 1] if lower_triangle else row
+            handle.write(f"{source}\t" + "\t".join([f"{x:.6f}" for x in cells]) + "\n")
+    return filepath
+
+
+def _get_tree_order(matrix):
+    """Leaf order of a single-linkage dendrogram on distances (matrix.py:673-686)."""
+    if not matrix.is_distance:
+        matrix = matrix.extract_submatrix(matrix.nodes)
+        matrix.invert()
+    z = linkage(matrix.to_ndarray(condensed=True), method="single")
+    return dendrogram(z, no_plot=True, get_leaves=True, count_sort="descending")["leaves"]

@@ -1,0 +1,64 @@
+"""The six pairwise metrics, same names and signatures as the reference's metrics.py.
+
+Each call packs the two genomes and runs the N = 2 case of the same HIP kernels that fill
+whole matrices, so a pairwise value and a matrix cell can never disagree.  ``source`` is
+the reference's source genome (anchor on ties, metrics.py:208-209).  No CPU fallback.
+
+Bulk use goes through ``matrix_de_novo`` (it recognises these callables and fills the
+whole matrix in one device pass); calling them in a Python loop is correct but slow.
+"""
+
+from phamclust_amd.genome import Genome
+from phamclust_amd.pack import pack_genomes
+
+
+def _pairwise(metric, source, target, as_distance):
+    if not isinstance(source, Genome) or not isinstance(target, Genome):
+        raise TypeError(f"cannot compare '{type(source)}' to '{type(target)}'")
+    from phamclust_amd.matrix import get_context
+    ctx = get_context()
+    ctx.upload(pack_genomes([source, target]))
+    return float(ctx.fill(metric, as_distance=as_distance)[0])
+
+
+def gene_content_similarity(source, target, as_distance=False):
+    """2|S n T| / (|S| + |T|) over pham sets (reference metrics.py:26-53)."""
+    return _pairwise("gcs", source, target, as_distance)
+
+
+def jaccard_coefficient(source, target, as_distance=False):
+    """|S n T| / |S u T| (reference metrics.py:56-80)."""
+    return _pairwise("jc", source, target, as_distance)
+
+
+def percentage_of_conserved_proteins(source, target, as_distance=False):
+    """Genes in shared phams / all genes, both genomes (reference metrics.py:83-115)."""
+    return _pairwise("pocp", source, target, as_distance)
+
+
+def alignment_fraction(source, target, as_distance=False):
+    """As pocp but weighted by translation length (reference metrics.py:118-157)."""
+    return _pairwise("af", source, target, as_distance)
+
+
+def average_aminoacid_identity(source, target, ppos=False, as_distance=False):
+    """Length-weighted identity of best-matching genes in shared phams, global alignment
+    BLOSUM62 11/1 (reference metrics.py:178-232)."""
+    if ppos:
+        raise NotImplementedError("ppos=True (percent positives) is not on the accelerated path; "
+                                  "no CLI route sets it (reference cli.py has no such flag)")
+    return _pairwise("aai", source, target, as_distance)
+
+
+def proteomic_equivalence_quotient(source, target, as_distance=False):
+    """round(af, 6) * round(aai, 6) (reference metrics.py:235-253)."""
+    return _pairwise("peq", source, target, as_distance)
+
+
+# callables that matrix_de_novo recognises and runs as one bulk device fill
+ACCELERATED = {gene_content_similarity: "gcs", jaccard_coefficient: "jc",
+               percentage_of_conserved_proteins: "pocp", alignment_fraction: "af",
+               average_aminoacid_identity: "aai", proteomic_equivalence_quotient: "peq"}
+
+__all__ = ["alignment_fraction", "average_aminoacid_identity", "gene_content_similarity",
+           "jaccard_coefficient", "percentage_of_conserved_proteins", "proteomic_equivalence_quotient"]

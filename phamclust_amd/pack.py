@@ -1,0 +1,135 @@
+"""Pack a name-sorted ``list[Genome]`` into the flat arrays the C-ABI consumes.
+
+This is the hand-over format of the drop-in boundary (``pc_packed`` in
+``include/phamclust_hip.h``).  List order is pair orientation: for a pair (s, t) with
+s < t, genome s is the reference's ``source`` and t its ``target``
+(reference scripts/phamclust.py:221 sorts by name before matrix_de_novo, and
+matrix.py:479-486 pairs ``genomes[i]`` with ``genomes[i+1:]``).
+
+Layout
+  bitmap     u64[N*W]   bit p of row g set iff genome g holds pham id p (W = ceil(P/64))
+  nph        i32[N]     distinct phams          == len(g.phams)
+  ngen       i32[N]     genes, paralogs incl.   == len(g)
+  tlen       i64[N]     summed translation length
+  gene_off   i64[N+1]   CSR: genes of genome g are [gene_off[g], gene_off[g+1])
+  gene_pham  i32[G]     pham id per gene; within a genome sorted ascending, stable in
+                        the genome's own list order for paralogs
+  seq_off    i64[G+1]   residues of gene k are [seq_off[k], seq_off[k+1])
+  residues   u8[R]      raw bytes of the translations (one byte per character)
+Pham ids are ranks of the sorted unique pham names.
+"""
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class PackedGenomes:
+    names: list
+    pham_names: list
+    n_genomes: int
+    n_phams: int
+    words_per_row: int
+    bitmap: np.ndarray
+    nph: np.ndarray
+    ngen: np.ndarray
+    tlen: np.ndarray
+    gene_off: np.ndarray
+    gene_pham: np.ndarray
+    seq_off: np.ndarray
+    residues: np.ndarray
+    _keepalive: list = field(default_factory=list, repr=False)
+
+    @property
+    def n_genes(self):
+        return int(self.gene_pham.shape[0])
+
+    @property
+    def n_pairs(self):
+        return self.n_genomes * (self.n_genomes - 1) // 2
+
+    def validate(self):
+        """Shape/consistency checks done on the host before any kernel sees the data."""
+        N, W, G = self.n_genomes, self.words_per_row, self.n_genes
+        assert self.bitmap.dtype == np.uint64 and self.bitmap.shape == (N * W,)
+        assert self.nph.dtype == np.int32 and self.nph.shape == (N,)
+        assert self.ngen.dtype == np.int32 and self.ngen.shape == (N,)
+        assert self.tlen.dtype == np.int64 and self.tlen.shape == (N,)
+        assert self.gene_off.dtype == np.int64 and self.gene_off.shape == (N + 1,)
+        assert self.gene_pham.dtype == np.int32
+        assert self.seq_off.dtype == np.int64 and self.seq_off.shape == (G + 1,)
+        assert self.residues.dtype == np.uint8
+        assert int(self.gene_off[-1]) == G and int(self.seq_off[-1]) == self.residues.shape[0]
+        assert W == max(1, (self.n_phams + 63) // 64)
+        for arr in (self.bitmap, self.nph, self.ngen, self.tlen, self.gene_off, self.gene_pham,
+                    self.seq_off, self.residues):
+            assert arr.flags["C_CONTIGUOUS"]
+        return self
+
+
+def _encode(translation):
+    try:
+        return translation.encode("latin-1")
+    except UnicodeEncodeError as exc:          # one byte per character is part of the contract
+        raise ValueError(f"translation contains a character outside latin-1: {exc}") from None
+
+
+def pack_genomes(genomes):
+    """Pack genomes (in the given order) into a :class:`PackedGenomes`."""
+    if len(genomes) == 0:
+        raise ValueError("need at least 1 genome to pack")
+    vocab = sorted({pham for g in genomes for pham in g.phams})
+    pham_id = {name: k for k, name in enumerate(vocab)}
+    N, P = len(genomes), len(vocab)
+    W = max(1, (P + 63) // 64)
+
+    bitmap = np.zeros((N, W), dtype=np.uint64)
+    nph = np.zeros(N, dtype=np.int32)
+    ngen = np.zeros(N, dtype=np.int32)
+    tlen = np.zeros(N, dtype=np.int64)
+    gene_off = np.zeros(N + 1, dtype=np.int64)
+    gene_pham, seq_len, chunks = [], [], []
+
+    for g_idx, genome in enumerate(genomes):
+        ids = sorted((pham_id[p], p) for p in genome.phams)
+        nph[g_idx] = len(ids)
+        count, total = 0, 0
+        cols = np.fromiter((i for i, _ in ids), dtype=np.int64, count=len(ids))
+        if len(ids):
+            np.bitwise_or.at(bitmap[g_idx], cols >> 6, np.uint64(1) << (cols & 63).astype(np.uint64))
+        for pid, pham in ids:
+            for translation in genome.phams[pham]:
+                raw = _encode(translation)
+                gene_pham.append(pid)
+                seq_len.append(len(raw))
+                chunks.append(raw)
+                count += 1
+                total += len(raw)
+        ngen[g_idx] = count
+        tlen[g_idx] = total
+        gene_off[g_idx + 1] = gene_off[g_idx] + count
+
+    G = len(gene_pham)
+    seq_off = np.zeros(G + 1, dtype=np.int64)
+    if G:
+        np.cumsum(np.asarray(seq_len, dtype=np.int64), out=seq_off[1:])
+    residues = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy() if G else np.zeros(0, np.uint8)
+    return PackedGenomes(
+        names=[g.name for g in genomes], pham_names=vocab, n_genomes=N, n_phams=P, words_per_row=W,
+        bitmap=np.ascontiguousarray(bitmap.reshape(-1)), nph=nph, ngen=ngen, tlen=tlen, gene_off=gene_off,
+        gene_pham=np.asarray(gene_pham, dtype=np.int32), seq_off=seq_off, residues=residues).validate()
+
+
+def unpack_genomes(packed):
+    """Inverse of :func:`pack_genomes` (used by the synthetic generator and tests)."""
+    from phamclust_amd.genome import Genome
+    genomes = []
+    res = packed.residues.tobytes()
+    for g_idx, name in enumerate(packed.names):
+        genome = Genome(name)
+        for k in range(int(packed.gene_off[g_idx]), int(packed.gene_off[g_idx + 1])):
+            seq = res[int(packed.seq_off[k]):int(packed.seq_off[k + 1])].decode("latin-1")
+            genome.add(packed.pham_names[int(packed.gene_pham[k])], seq)
+        genomes.append(genome)
+    return genomes

@@ -1,0 +1,206 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box).  Every value computed here comes
+through the C-ABI of libphamclust_hip.so; the oracle and the golden fixtures are the checkers.
+
+Bars (north_star): gcs / jc / pocp bit-exact; af / aai / peq within 1e-6 (in practice the
+HIP path reproduces the oracle bit for bit, which these tests also record); integer
+alignment outputs (n_ident, n_diag) exactly equal to the oracle's.
+aai / peq fixtures are "oracle_nw" class: parity vs parasail's co-optimal ties is unpinned.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import ALL_METRICS, SET_METRICS, golden_file, read_adjacency_condensed, read_lower_triangle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_golden_distance(gpu_ctx, small_packed, metric):
+    names, gold, _ = read_lower_triangle(golden_file(metric))
+    assert names == small_packed.names
+    got = gpu_ctx.upload(small_packed).fill(metric, as_distance=True)
+    if metric in ("gcs", "jc", "pocp"):
+        assert np.array_equal(got, gold)
+    else:
+        assert np.max(np.abs(got - gold)) <= TOL
+        assert np.array_equal(got, gold), "HIP path is expected to reproduce the fixture bit for bit"
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_golden_similarity(gpu_ctx, small_packed, metric):
+    gold, _ = read_adjacency_condensed(golden_file(metric, "similarity"), small_packed.names)
+    got = gpu_ctx.upload(small_packed).fill(metric, as_distance=False)
+    if metric in ("gcs", "jc", "pocp"):
+        assert np.array_equal(got, gold)
+    else:
+        assert np.max(np.abs(got - gold)) <= TOL
+
+
+@pytest.mark.parametrize("n,p,seed", [(97, 600, 3), (200, 5000, None)])
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_synth_vs_oracle(gpu_ctx, native_built, metric, n, p, seed):
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(n, p, seed)
+    got = gpu_ctx.upload(packed).fill(metric, as_distance=True)
+    want = O.fill(packed, metric, as_distance=True)
+    assert got.shape == want.shape == (n * (n - 1) // 2,)
+    assert np.array_equal(got, want)
+    assert got.min() >= 0.0 and got.max() <= 1.0
+
+
+@pytest.mark.parametrize("variant", [0, -1])
+def test_align_pairs_integer_outputs(gpu_ctx, native_built, variant):
+    """(n_ident, n_diag) of every alignment == the oracle's, exactly."""
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(60, 300, seed=11)
+    rng = np.random.default_rng(5)
+    g = packed.n_genes
+    a = rng.integers(0, g, 4000).astype(np.int32)
+    b = rng.integers(0, g, 4000).astype(np.int32)
+    b[:500] = b[0]                                   # a long bucket: many rows against one column gene
+    gpu_ctx.upload(packed)
+    ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
+    _, want_i, want_d = O.nw_batch(packed.residues, packed.seq_off, a, b)
+    assert np.array_equal(ident, want_i)
+    assert np.array_equal(diag, want_d)
+
+
+def test_round6_matches_python(gpu_ctx):
+    rng = np.random.default_rng(9)
+    xs = np.concatenate([
+        rng.random(200000),
+        (rng.integers(0, 1000000, 100000) + 0.5) / 1e6,                 # decimal ties (inexact in binary)
+        rng.integers(0, 2 ** 20, 100000) / 2.0 ** rng.integers(1, 24, 100000),   # exact binary ties
+        rng.integers(0, 400, 100000) / np.maximum(1, rng.integers(1, 700, 100000)),
+        np.array([0.0, 1.0, 0.5, 1 / 128, 3 / 128, 1 / 640, 5e-7, 4.9999999e-7, 1e-300, 0.9999995, 0.9999994999]),
+    ])
+    xs = xs[xs <= 1.0]
+    got = gpu_ctx.round6(xs)
+    want = np.array([round(float(x), 6) for x in xs])
+    assert np.array_equal(got, want)
+
+
+def test_edge_cases(gpu_ctx, native_built):
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    # single genome: no pairs
+    g0 = Genome("only"); g0.add("p1", "MKV")
+    out = gpu_ctx.upload(pack_genomes([g0])).fill("peq")
+    assert out.shape == (0,)
+    # two genomes sharing nothing: every metric similarity 0 -> distance 1
+    g1 = Genome("a"); g1.add("p1", "MKV")
+    g2 = Genome("b"); g2.add("p2", "MKV")
+    pk = pack_genomes([g1, g2])
+    for metric in ALL_METRICS:
+        assert gpu_ctx.upload(pk).fill(metric, as_distance=True)[0] == 1.0
+        assert gpu_ctx.upload(pk).fill(metric, as_distance=False)[0] == 0.0
+    # all-"M" two-column style input: aai == 1 wherever phams are shared, peq == af
+    gs = []
+    for k in range(6):
+        g = Genome(f"m{k}")
+        for p in range(k, k + 4):
+            g.add(f"p{p}")
+        gs.append(g)
+    pk = pack_genomes(gs)
+    gpu_ctx.upload(pk)
+    aai = gpu_ctx.fill("aai", as_distance=False)
+    af = gpu_ctx.fill("af", as_distance=False)
+    pocp = gpu_ctx.fill("pocp", as_distance=False)
+    peq = gpu_ctx.fill("peq", as_distance=False)
+    shared = gpu_ctx.fill("gcs", as_distance=False) > 0
+    assert np.array_equal(aai[shared], np.ones(shared.sum()))
+    assert np.array_equal(aai[~shared], np.zeros((~shared).sum()))
+    assert np.array_equal(af, pocp)
+    assert np.array_equal(peq, af)
+    # empty translation under aai: refused loudly, like the reference (parasail cannot align it)
+    from phamclust_amd.hip import HipLibraryError
+    g3 = Genome("e1"); g3.add("p1", "")
+    g4 = Genome("e2"); g4.add("p1", "MK")
+    gpu_ctx.upload(pack_genomes([g3, g4]))
+    with pytest.raises(HipLibraryError):
+        gpu_ctx.fill("aai")
+    assert gpu_ctx.fill("af", as_distance=False)[0] == 1.0
+
+
+def test_long_and_ragged_sequences(gpu_ctx, native_built):
+    """Column sequences from 1 residue up to beyond the systolic kernels' reach."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(21)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    lens = [1, 2, 3, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 513, 1279, 1280, 1281, 1500, 2100]
+    gs = []
+    for gi in range(3):
+        g = Genome(f"g{gi}")
+        for k, ln in enumerate(lens):
+            base = "".join(aa[rng.integers(0, 20, ln)])
+            g.add(f"p{k:02d}", base)
+            if gi == 1 and ln > 3:                 # a paralog with an indel, so anchors have choices
+                g.add(f"p{k:02d}", base[: ln // 2] + base[ln // 2 + 2:])
+        gs.append(g)
+    pk = pack_genomes(gs)
+    gpu_ctx.upload(pk)
+    for metric in ("aai", "peq"):
+        assert np.array_equal(gpu_ctx.fill(metric), O.fill(pk, metric))
+    g = pk.n_genes
+    a, b = np.meshgrid(np.arange(g, dtype=np.int32), np.arange(g, dtype=np.int32))
+    a, b = a.ravel(), b.ravel()
+    keep = rng.random(a.shape[0]) < 0.15
+    a, b = a[keep], b[keep]
+    ident, diag = gpu_ctx.align_pairs(a, b)
+    _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+    assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
+
+
+def test_shard_and_assemble_single_gpu(gpu_ctx, native_built):
+    """Shard-local fills of every rank of a 3-way and a 4-way split, gathered by hand and
+    assembled on the device, equal the unsharded condensed result."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(83, 500, seed=2)
+    gpu_ctx.upload(packed)
+    for metric in ("jc", "af", "peq"):
+        want = gpu_ctx.fill(metric)
+        for world in (3, 4):
+            strides, parts = set(), []
+            for rank in range(world):
+                gpu_ctx.set_shard(rank, world)
+                stride = gpu_ctx.shard_stride()
+                strides.add(stride)
+                buf = torch.full((stride,), -1.0, dtype=torch.float64, device="cuda:0")
+                gpu_ctx.fill_shard_dev(metric, True, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                parts.append(buf)
+            assert len(strides) == 1
+            gathered = torch.cat(parts)
+            out = torch.empty(packed.n_pairs, dtype=torch.float64, device="cuda:0")
+            gpu_ctx.assemble_dev(gathered.data_ptr(), world, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+        gpu_ctx.set_shard(0, 1)
+
+
+def test_matrix_de_novo_drop_in(native_built, small_genomes):
+    """The reference-shaped entry point: matrix_de_novo(genomes, METRICS[m], cpus)."""
+    from phamclust_amd.cli import METRICS
+    from phamclust_amd.matrix import matrix_de_novo
+    for metric in ("gcs", "peq"):
+        names, gold, diag = read_lower_triangle(golden_file(metric))
+        m = matrix_de_novo(small_genomes, METRICS[metric], 4)
+        assert m.is_distance and m.nodes == names
+        assert np.array_equal(m.to_ndarray(condensed=True), gold)
+        assert all(m.get_weight(n, n) == 0.0 for n in names)
+    # pairwise call of the same callable agrees with the matrix cell
+    s, t = small_genomes[3], small_genomes[17]
+    assert METRICS["peq"](s, t, as_distance=True) == m.get_weight(s.name, t.name)
