@@ -58,9 +58,10 @@ __device__ __forceinline__ PcCell pc_cell(int Hol, int El, uint32_t SHl, uint32_
     c.F = max(Hou, Fe);
     c.SF = (Hou > Fe) ? SHu : SFu;
     const int D = Hod + sp;
-    const int H = max(D, max(c.E, c.F));
+    const int H = max(max(D, c.E), c.F);
     const uint32_t SD = SHd + 0x10000u + (eq ? 1u : 0u);
-    c.SH = (H == D) ? SD : ((H == c.F) ? c.SF : c.SE);
+    const uint32_t ST = (H == c.F) ? c.SF : c.SE;   // two flat selects: nested ?: becomes control flow
+    c.SH = (H == D) ? SD : ST;
     c.Ho = H - PC_OPEN;
     return c;
 }
@@ -119,6 +120,193 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Systolic kernel (the production path): wavefront-level anti-diagonal sweep.
+//
+// One wave per task.  The task's column sequence b (lb residues) is cut into strips of W
+// columns, one strip per lane; G = ceil(lb/W) consecutive lanes form a segment, and
+// nseg = floor(64/G) segments of the same b work side by side on different row
+// sequences.  Lane k of a segment keeps the previous row of its W columns (Ho, F and the
+// two stats) in registers and at step t processes row t-k of the segment's row stream:
+// what it needs from the left neighbour -- Ho, E, stats of that lane's last column, and
+// the row's residue -- arrives by DPP wave_shr:1 from the neighbour's previous step, so
+// the active cells at any step form an anti-diagonal and no LDS or barrier is involved in
+// the recurrence.  The head lane of a segment feeds the stream: for every alignment a
+// "virtual row -1" (flag RESET: previous row := -inf, which makes the ordinary recurrence
+// produce the boundary H(-1,j) = -(11+j) with zero stats) followed by its la rows, back
+// to back, so the pipeline fills once per task, not once per alignment.  The lane holding
+// column lb-1 emits (n_ident, aln_len) when a row flagged LAST leaves it.
+// Substitution scores come from a per-task profile in LDS: prof[r][k][c] = S(r, b_j)+11,
+// one ds_read of W bytes per lane per row.
+// ---------------------------------------------------------------------------------
+#define PCF_RESET 0x100
+#define PCF_LAST 0x200
+
+__device__ __forceinline__ int pc_shr1(int v) {                        // lane k <- lane k-1 (lane 0 keeps 0)
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);  // DPP wave_shr:1
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+                                                    const int32_t* __restrict__ bucket_row,
+                                                    const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res) {
+    constexpr int ND = (W + 3) / 4;                 // profile dwords per lane per residue row
+    extern __shared__ uint32_t prof[];              // [24][G][ND]
+    __shared__ int8_t tab[24][24];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 576; i += 64) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
+
+    const PcTask tk = tasks[blockIdx.x];
+    const int lb = d.gene_len[tk.gene];
+    const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
+    const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
+    const int nseg = 64 / G;
+    const int seg = lane / G, k = lane - seg * G;
+    const bool in_seg = seg < nseg;
+    const bool is_head = in_seg && k == 0;
+    const int k_out = (lb - 1) / W, c_out = (lb - 1) - k_out * W;
+    const bool is_out = in_seg && k == k_out;
+
+    int bc[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) { const int j = k * W + c; bc[c] = (in_seg && j < lb) ? (int)bp[j] : PC_PADCODE; }
+    __syncthreads();
+    if (seg == 0) {                                  // segment 0 writes the shared profile
+#pragma unroll 1
+        for (int r = 0; r < 24; ++r) {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = q * 4 + e;
+                    if (c < W) v |= (uint32_t)(uint8_t)tab[r][min(bc[c], 23)] << (8 * e);
+                }
+                prof[(r * G + k) * ND + q] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- head-lane stream state ---------------------------------------------------
+    int h_row = tk.begin + seg;                      // bucket row of the current alignment
+    int h_la = 0, h_i = -1;                          // rows, next row to emit (-1 = virtual row)
+    const uint8_t* h_ptr = d.codes;
+    int n_la = 0; const uint8_t* n_ptr = d.codes;    // prefetched next alignment
+    bool h_live = false;
+    int T = 0;
+    if (is_head) {
+        int L = 0;
+        for (int r = h_row; r < tk.end; r += nseg) L += d.gene_len[bucket_row[r]] + 1;
+        T = L;
+        if (h_row < tk.end) {
+            const int ga = bucket_row[h_row]; h_la = d.gene_len[ga]; h_ptr = d.codes + d.gene_off[ga]; h_live = true;
+            if (h_row + nseg < tk.end) { const int gn = bucket_row[h_row + nseg]; n_la = d.gene_len[gn]; n_ptr = d.codes + d.gene_off[gn]; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) T = max(T, __shfl_xor(T, o));
+    T += G - 1;
+    int out_row = tk.begin + seg;                    // out lane: bucket row of the next result
+
+    int Hou[W], Fu[W]; uint32_t SHu[W], SFu[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; SHu[c] = 0; SFu[c] = 0; }
+    int o_a = 0, o_Ho = 0, o_E = PC_NEG; uint32_t o_SH = 0, o_SE = 0;   // my last column, previous step
+    int p_Hol = PC_NEG; uint32_t p_SHl = 0;                              // what I received last step (diag of slot 0)
+    int a_nxt = 0;                                                        // head: residue byte loaded one step ahead
+    if (is_head && h_live) a_nxt = h_ptr[0];
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        int a = pc_shr1(o_a);
+        int Hol = pc_shr1(o_Ho);
+        int El = pc_shr1(o_E);
+        uint32_t SHl = (uint32_t)pc_shr1((int)o_SH);
+        uint32_t SEl = (uint32_t)pc_shr1((int)o_SE);
+        if (is_head) {
+            El = PC_NEG; SHl = 0; SEl = 0;
+            if (!h_live) { a = 0; Hol = 0; }
+            else if (h_i < 0) { a = PCF_RESET; Hol = -PC_OPEN; h_i = 0; }                    // H(-1,-1) = 0
+            else {
+                a = a_nxt | (h_i == h_la - 1 ? PCF_LAST : 0);
+                Hol = -(PC_OPEN + h_i * PC_EXT) - PC_OPEN;                                    // H(i,-1)
+                ++h_i;
+                if (h_i == h_la) {                                                           // advance to the next alignment
+                    h_row += nseg; h_i = -1; h_la = n_la; h_ptr = n_ptr; h_live = h_row < tk.end;
+                    if (h_row + nseg < tk.end) { const int gn = bucket_row[h_row + nseg]; n_la = d.gene_len[gn]; n_ptr = d.codes + d.gene_off[gn]; }
+                }
+            }
+            if (h_live) a_nxt = h_ptr[h_i < 0 ? 0 : h_i];                                   // prefetch for the next step
+        }
+        int Hod = p_Hol; uint32_t SHd = p_SHl;
+        p_Hol = Hol; p_SHl = SHl;
+        if (a & PCF_RESET) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; }
+            Hod = PC_NEG;
+        }
+        const int ac = a & 0xff;
+        const uint32_t* pr = prof + (min(ac, 23) * G + k) * ND;
+        uint32_t pw[ND];
+#pragma unroll
+        for (int q = 0; q < ND; ++q) pw[q] = pr[q];
+        int E_last = PC_NEG; uint32_t SE_last = 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const int sp = (int)((pw[c >> 2] >> (8 * (c & 3))) & 0xffu);
+            const PcCell x = pc_cell(Hol, El, SHl, SEl, Hou[c], Fu[c], SHu[c], SFu[c], Hod, SHd, sp, ac == bc[c]);
+            Hod = Hou[c]; SHd = SHu[c];
+            Hou[c] = x.Ho; Fu[c] = x.F; SHu[c] = x.SH; SFu[c] = x.SF;
+            Hol = x.Ho; El = x.E; SHl = x.SH; SEl = x.SE;
+            E_last = x.E; SE_last = x.SE;
+        }
+        o_a = a; o_Ho = Hol; o_E = E_last; o_SH = SHl; o_SE = SE_last;
+        if ((a & PCF_LAST) && is_out) {
+            uint32_t st = SHu[0];
+#pragma unroll
+            for (int c = 1; c < W; ++c) if (c == c_out) st = SHu[c];
+            const int la = d.gene_len[bucket_row[out_row]];
+            res[bucket_dest[out_row]] = make_uint2(st & 0xffffu, (uint32_t)(la + lb) - (st >> 16));
+            out_row += nseg;
+        }
+    }
+}
+
+// columns-per-lane of the compiled systolic variants
+static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20};
+static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
+
+int pc_nw_num_variants() { return g_num_variants; }
+int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
+
+// Variant for a column gene of lb residues: minimise modelled instruction slots per
+// alignment row, (19 W + 45) / nseg, over the variants whose 64*W columns cover lb.
+int pc_nw_choose_variant(int lb) {
+    if (lb <= 0) return -1;
+    int best = -1; double best_cost = 0;
+    for (int v = 0; v < g_num_variants; ++v) {
+        const int W = g_variant_w[v];
+        const int G = (lb + W - 1) / W;
+        if (G > 64) continue;
+        const int nseg = 64 / G;
+        const double cost = (19.0 * W + 45.0) / nseg;
+        if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
+    }
+    return best;
+}
+
+template <int W>
+static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
+                           const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
+    const int ND = (W + 3) / 4;
+    int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
+    const size_t lds = (size_t)24 * Gmax * ND * 4;
+    hipLaunchKernelGGL(k_nw_systolic<W>, dim3((unsigned)ntasks), dim3(64), lds, st, d, tasks, bucket_row, bucket_dest, res);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d> launch: %s", W, hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
 size_t pc_nw_fallback_scratch_bytes(int max_lb) {
     size_t per_block = (size_t)64 * (size_t)max_lb * sizeof(int4);
     size_t budget = (size_t)2 << 30;
@@ -128,14 +316,21 @@ size_t pc_nw_fallback_scratch_bytes(int max_lb) {
     return blocks * per_block;
 }
 
-int pc_nw_num_variants() { return 0; }
-int pc_nw_variant_w(int) { return 0; }
-int pc_nw_choose_variant(int) { return -1; }
-
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
-    if (variant >= 0) { pc_set_error("pc_launch_nw: unknown variant %d", variant); return PC_ERR_ARG; }
+    if (variant >= 0) {
+        if (variant >= g_num_variants || max_lb > 64 * g_variant_w[variant]) {
+            pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
+        }
+        switch (g_variant_w[variant]) {
+#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+        PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
+        PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(16) PC_CASE(18) PC_CASE(20)
+#undef PC_CASE
+        default: pc_set_error("pc_launch_nw: no kernel for variant %d", variant); return PC_ERR_ARG;
+        }
+    }
     // general kernel: one scratch slab of 64 * max_lb cells per resident workgroup
     const size_t per_block = (size_t)64 * (size_t)(max_lb > 0 ? max_lb : 1) * sizeof(int4);
     size_t blocks = scratch ? scratch_bytes / per_block : 0;

@@ -56,6 +56,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(f"{LIB_PATH} not found: build it with `python -m phamclust_amd.build` "
                               f"(there is no CPU fallback)")
+    # torch ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both open
+    # the GPU.  Importing torch first makes our library bind to the runtime torch uses, so
+    # torch tensors, streams and torch.distributed (RCCL) share one device context with it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as exc:
