@@ -1,0 +1,267 @@
+"""CPU tests of the host side: Genome / SymMatrix surface, packing, synthetic data,
+TSV I/O, the C-ABI export list, and loud failure without the HIP library."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, golden_file, read_lower_triangle
+
+
+# ---- Genome ---------------------------------------------------------------------------
+def test_genome_surface():
+    from phamclust_amd.genome import Genome
+    g = Genome("g1")
+    g.add("p1", "MKV"); g.add("p2"); g.add("p1", "MKL")
+    assert g.phams == {"p1": ["MKV", "MKL"], "p2": ["M"]}
+    assert len(g) == 3 and len(g.phams) == 2 and "p1" in g and "zz" not in g
+    assert g["p1"] == ["MKV", "MKL"]
+    with pytest.raises(KeyError):
+        g["zz"]
+    with pytest.raises(TypeError):
+        g.add(1, "M")
+    with pytest.raises(TypeError):
+        g.add("p", 5)
+    with pytest.raises(TypeError):
+        1 in g
+    h = Genome("g2"); h.add("p2", "MA"); h.add("p3", "MC")
+    assert g & h == {"p2"} == g.intersection(h)
+    assert g | h == {"p1", "p2", "p3"} == g.union(h)
+    assert g - h == {"p1"} == g.difference(h)
+    assert g ^ h == {"p1", "p3"} == g.symmetric_difference(h)
+    with pytest.raises(TypeError):
+        g & "x"
+    assert str(g) == ">name=g1|pham=p1|n=1\nMKV\n>name=g1|pham=p1|n=2\nMKL\n>name=g1|pham=p2|n=1\nM\n"
+    assert h < g and g.pop("p2") == ["M"] and g.pop("p2") is None
+
+
+def test_genome_fasta_roundtrip(tmp_path):
+    from phamclust_amd.genome import Genome, GenomeLoadError
+    g = Genome("g1"); g.add("p1", "MKV"); g.add("p1", "MKL"); g.add("p9", "MW")
+    path = g.save(tmp_path / "g1.fasta")
+    h = Genome("g1"); h.load(path)
+    assert h.phams == g.phams
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">name=x|n=1\nMK\n")
+    with pytest.raises(GenomeLoadError):
+        Genome("x").load(bad)
+
+
+# ---- packing --------------------------------------------------------------------------
+def test_pack_layout(small_genomes, small_packed):
+    pk = small_packed
+    assert pk.names == [g.name for g in small_genomes] == sorted(pk.names)
+    assert pk.n_phams == len({p for g in small_genomes for p in g.phams})
+    for i, g in enumerate(small_genomes):
+        assert pk.nph[i] == len(g.phams) and pk.ngen[i] == len(g)
+        assert pk.tlen[i] == sum(len(t) for ts in g.phams.values() for t in ts)
+        ids = pk.gene_pham[pk.gene_off[i]:pk.gene_off[i + 1]]
+        assert (np.diff(ids) >= 0).all()
+        row = pk.bitmap[i * pk.words_per_row:(i + 1) * pk.words_per_row]
+        assert sum(bin(int(w)).count("1") for w in row) == len(g.phams)
+    from phamclust_amd.pack import unpack_genomes
+    back = unpack_genomes(pk)
+    for g, h in zip(small_genomes, back):
+        assert {p: ts for p, ts in g.phams.items()} == {p: ts for p, ts in h.phams.items()}
+
+
+def test_pack_rejects_empty_and_wide_chars():
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    with pytest.raises(ValueError):
+        pack_genomes([])
+    g = Genome("g"); g.add("p", "MK中")
+    with pytest.raises(ValueError):
+        pack_genomes([g])
+
+
+def test_synth_is_deterministic_and_consistent(native_built):
+    from phamclust_amd.pack import pack_genomes, unpack_genomes
+    from phamclust_amd.synth import synth_packed
+    a, b = synth_packed(50, 700), synth_packed(50, 700)
+    for f in ("bitmap", "nph", "ngen", "tlen", "gene_off", "gene_pham", "seq_off", "residues"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+    c = synth_packed(50, 700, seed=1)
+    assert not np.array_equal(a.residues[:1000], c.residues[:1000])
+    again = pack_genomes(unpack_genomes(a))          # the generator's packing == pack_genomes of its genomes
+    for f in ("bitmap", "nph", "ngen", "tlen", "gene_off", "gene_pham", "seq_off", "residues"):
+        assert np.array_equal(getattr(a, f), getattr(again, f))
+    assert a.names[0] == "synth_000000" and 60 <= a.nph.min() and a.nph.max() <= 140
+    lens = np.diff(a.seq_off)
+    assert lens.min() >= 1 and lens.max() <= 1500 and 150 < lens.mean() < 280
+    assert set(np.unique(a.residues).tolist()) <= set(map(ord, "ACDEFGHIKLMNPQRSTVWY"))
+
+
+# ---- SymMatrix ------------------------------------------------------------------------
+def _toy():
+    from phamclust_amd.matrix import SymMatrix
+    m = SymMatrix(["b", "a", "c"], is_distance=True)
+    for n in "abc":
+        m.set_weight(n, n, 0.0)
+    m.set_weight("a", "b", 0.1234564)
+    m.set_weight("c", "a", 0.5)
+    m.set_weight("b", "c", 0.9)
+    return m
+
+
+def test_symmatrix_basic_surface():
+    m = _toy()
+    assert len(m) == 3 and m.nodes == ["b", "a", "c"] and m.is_distance
+    assert m.get_weight("b", "a") == m.get_weight("a", "b") == 0.123456          # rounded on write
+    assert list(m) == [("b", "b", 0.0), ("b", "a", 0.123456), ("b", "c", 0.9),
+                       ("a", "a", 0.0), ("a", "c", 0.5), ("c", "c", 0.0)]
+    assert [r for _, r in m.iterrows()] == [[0.0, 0.123456, 0.9], [0.123456, 0.0, 0.5], [0.9, 0.5, 0.0]]
+    assert m["a"] == {"a": 0.0, "b": 0.123456, "c": 0.5} and m["c"] == {"c": 0.0}  # string-ordered keys
+    with pytest.raises(ValueError):
+        m.set_weight("a", "b", 1.5)
+    with pytest.raises(KeyError):
+        m.set_weight("a", "zz", 0.5)
+    with pytest.raises(KeyError):
+        m.get_weight("zz", "a")
+    with pytest.raises(TypeError):
+        5 in m
+    m.lock()
+    with pytest.raises(AttributeError):
+        m.set_weight("a", "b", 0.2)
+    assert m.is_locked()
+    m.unlock()
+    assert m.diameter == 0.9
+    assert np.array_equal(m.to_ndarray(condensed=True), np.array([0.123456, 0.9, 0.5]))
+    assert str(m).splitlines()[0] == "3" and str(m).splitlines()[1].startswith("b" + " " * 23 + "\t0.000000\t0.123456")
+    from phamclust_amd.matrix import SymMatrix
+    assert SymMatrix(["x"]) < m
+    unset = SymMatrix(["x", "y"])
+    assert unset.get_weight("x", "y") is None
+
+
+def test_symmatrix_medoid_invert_extract_reorder():
+    from phamclust_amd.matrix import SymMatrix
+    m = _toy()
+    # medoid: mean over N+1 incident weights with the diagonal counted twice, ties by node order
+    central = {"b": (0.0 + 0.0 + 0.123456 + 0.9) / 4, "a": (0.123456 + 0.0 + 0.0 + 0.5) / 4, "c": (0.9 + 0.5 + 0.0 + 0.0) / 4}
+    assert m.medoid[0] == "a" and m.medoid[1] == pytest.approx(central["a"])
+    assert m.anti_medoid[0] == "c"
+    sub = m.extract_submatrix(["c", "a"])
+    assert sub.nodes == ["c", "a"] and sub.get_weight("a", "c") == 0.5 and sub.is_distance
+    with pytest.raises(KeyError):
+        m.extract_submatrix(["a", "zz"])
+    m.invert()
+    assert not m.is_distance and m.get_weight("a", "b") == 0.876544 and m.get_weight("a", "a") == 1.0
+    assert m.medoid[0] == "a"                       # similarity: largest mean
+    with pytest.raises(ValueError):
+        m.diameter
+    m.invert()
+    m.reorder(["a", "b", "c"])
+    assert m.nodes == ["a", "b", "c"] and list(m)[1] == ("a", "b", 0.123456)
+    with pytest.raises(ValueError):
+        m.reorder(["a", "b"])
+    m.reorder()                                     # single-linkage tree order
+    assert sorted(m.nodes) == ["a", "b", "c"]
+    assert m.nearest_neighbors("a", 0.6) == ["b", "c"]
+    m.append_node("d", {"a": 0.2, "b": 0.3, "c": 0.4, "d": 0.0})
+    assert len(m) == 4 and m.get_weight("d", "b") == 0.3
+    with pytest.raises(KeyError):
+        m.append_node("d", {"a": 0.2, "b": 0.3, "c": 0.4, "d": 0.0})
+    with pytest.raises(ValueError):
+        m.append_node("e", {"a": 0.2, "b": 0.3, "c": 0.4, "d": 0.1, "e": 1.0})
+    mean, sd, skew = m.statistics
+    assert mean == pytest.approx(np.mean([0.123456, 0.5, 0.9, 0.2, 0.3, 0.4]))
+    one = SymMatrix(["x"], True); one.set_weight("x", "x", 0.0)
+    assert one.statistics == (0.0, 0.0, 0.0)
+
+
+def test_from_condensed_and_tsv_roundtrip(tmp_path):
+    from phamclust_amd.matrix import (SymMatrix, matrix_from_adjacency, matrix_from_squareform,
+                                      matrix_to_adjacency, matrix_to_squareform)
+    names, gold, diag = read_lower_triangle(golden_file("jc"))
+    m = SymMatrix.from_condensed(names, gold, is_distance=True)
+    assert np.array_equal(m.to_ndarray(condensed=True), gold)
+    # lower-triangle writer is byte-identical to the file the reference wrote
+    out = matrix_to_squareform(m, tmp_path / "lt.tsv", lower_triangle=True)
+    assert open(out).read() == open(golden_file("jc")).read()
+    back = matrix_from_squareform(out)
+    assert back.is_distance and back.nodes == names and np.array_equal(back.to_ndarray(condensed=True), gold)
+    full = matrix_to_squareform(m, tmp_path / "sq.tsv")
+    assert open(full).readline().rstrip().split("\t") == [str(len(names))] + names
+    assert np.array_equal(matrix_from_squareform(full).to_ndarray(condensed=True), gold)
+    m.invert()
+    adj = matrix_to_adjacency(m, tmp_path / "adj.tsv")
+    assert open(adj).read() == open(golden_file("jc", "similarity")).read()
+    again = matrix_from_adjacency(adj)
+    assert not again.is_distance and np.array_equal(again.to_ndarray(), m.to_ndarray())
+    with pytest.raises(ValueError):
+        SymMatrix.from_condensed(names, gold[:-1])
+
+
+def test_matrix_de_novo_generic_callable_and_errors():
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.matrix import _outside_in_index_iterator, matrix_de_novo
+    assert list(_outside_in_index_iterator(5)) == [0, 4, 1, 3, 2]          # reference matrix.py:415-416
+    assert list(_outside_in_index_iterator(4)) == [0, 3, 1, 2] and list(_outside_in_index_iterator(1)) == [0]
+    with pytest.raises(ValueError):
+        matrix_de_novo([], lambda s, t, as_distance=False: 0.0, 1)
+    gs = []
+    for k in range(4):
+        g = Genome(f"g{k}")
+        for p in range(k + 1):
+            g.add(f"p{p}")
+        gs.append(g)
+
+    def overlap(source, target, as_distance=False):       # any user callable: generic per-pair path
+        sim = len(source & target) / 4.0
+        return round(1.0 - sim, 6) if as_distance else round(sim, 6)
+
+    m = matrix_de_novo(gs, overlap, 2)
+    assert m.is_distance and m.get_weight("g0", "g3") == 0.75 and m.get_weight("g2", "g3") == 0.25
+    assert all(m.get_weight(g.name, g.name) == 0.0 for g in gs)
+    sim = matrix_de_novo(gs, overlap, 1, as_distance=False)
+    assert not sim.is_distance and sim.get_weight("g1", "g1") == 1.0 and sim.get_weight("g1", "g2") == 0.5
+
+
+def test_cli_surface():
+    from phamclust_amd import cli
+    assert list(cli.METRICS) == ["gcs", "jc", "pocp", "af", "aai", "peq"]
+    args = cli.parse_args(["in.tsv", "out"])
+    assert args.metric == "peq" and args.nr_thresh == 0.75 and args.clu_thresh == 0.25 and args.sub_thresh == 0.6
+    assert args.nr_linkage == "complete" and args.clu_linkage == "average" and args.sub_linkage == "single" and args.k_min == 6
+    assert cli.parse_args(["in.tsv", "out", "-m", "jc", "-t", "3"]).metric == "jc"
+    with pytest.raises(SystemExit):
+        cli.parse_args(["in.tsv", "out", "-m", "nope"])
+
+
+# ---- C-ABI ------------------------------------------------------------------------------
+def test_abi_exports_match_header(native_built):
+    """The library loads and exports exactly the functions include/phamclust_hip.h declares
+    (no compute calls here: there is no GPU on the CPU box)."""
+    from phamclust_amd import hip
+    header = open(os.path.join(REPO, "include", "phamclust_hip.h")).read()
+    declared = set(re.findall(r"\b(pc_[a-z0-9_]+)\s*\(", header)) - {"pc_ctx"}
+    assert declared == set(hip.EXPORTS)
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.load().pc_version() == 100
+    assert ctypes.sizeof(hip.PcPacked) == 16 + 8 * 8 and ctypes.sizeof(hip.PcStats) == 5 * 8 + 2 * 4 + 4 * 4
+
+
+def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
+    from phamclust_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(hip.HipLibraryError):
+        hip.load()
+    with pytest.raises(hip.HipLibraryError):
+        hip.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under phamclust_amd/ may reference it."""
+    pkg = os.path.join(REPO, "phamclust_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "pc_oracle" not in text, f

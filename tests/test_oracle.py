@@ -1,0 +1,182 @@
+"""CPU tests of the oracle itself (no GPU): golden fixtures from the live reference,
+the two aligner formulations, math-pinned known answers, Python's round()."""
+
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ALL_METRICS, SET_METRICS, golden_file, read_adjacency_condensed, read_lower_triangle
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def test_blosum62_checksums(O):
+    L = O.lib()
+    m = [[L.pco_blosum62(i, j) for j in range(24)] for i in range(24)]
+    assert all(m[i][j] == m[j][i] for i in range(24) for j in range(24))
+    assert [m[i][i] for i in range(24)] == [4, 5, 6, 6, 9, 5, 5, 6, 8, 4, 4, 5, 5, 6, 7, 4, 5, 11, 7, 4, 4, 4, -1, 1]
+    assert sum(m[i][j] for i in range(20) for j in range(20)) == -426
+    assert sum(map(sum, m)) == -726
+    assert min(map(min, m)) == -4 and max(map(max, m)) == 11
+    assert L.pco_map(ord("a")) == L.pco_map(ord("A")) == 0 and L.pco_map(ord("J")) == 23 == L.pco_map(ord("*"))
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_c_oracle_vs_golden(O, small_packed, metric):
+    """gcs/jc/pocp/af fixtures are pure reference output; aai/peq fixtures are the reference's
+    metrics.py driven by this oracle's aligner (class "oracle_nw")."""
+    names, gold, diag = read_lower_triangle(golden_file(metric))
+    assert names == small_packed.names and not diag.any()
+    assert np.array_equal(O.fill(small_packed, metric, as_distance=True), gold)
+    gsim, dsim = read_adjacency_condensed(golden_file(metric, "similarity"), names)
+    assert (dsim == 1.0).all()
+    assert np.array_equal(O.fill(small_packed, metric, as_distance=False), gsim)
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_python_restatement_vs_golden(O, small_genomes, metric):
+    names, gold, _ = read_lower_triangle(golden_file(metric))
+    f = O.PY_METRICS[metric]
+    n = len(small_genomes)
+    vals = [f(small_genomes[i], small_genomes[j], as_distance=True) for i in range(n) for j in range(i + 1, n)]
+    assert np.array_equal(np.array(vals), gold)
+
+
+def test_aligner_formulations_agree(O):
+    rng = random.Random(1)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    for it in range(4000):
+        alpha = aa[:3] if it % 3 == 0 else aa           # a 3-letter alphabet forces many co-optimal ties
+        a = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 48)))
+        b = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 48)))
+        tb = O.nw_traceback(a, b)
+        score, ident, diag = O.nw_stats(a, b)
+        assert score == tb.score
+        assert ident == tb.comp.count("|")
+        assert len(tb.query) == len(tb.ref) == len(tb.comp) == len(a) + len(b) - diag
+        assert tb.query.replace("-", "") == a and tb.ref.replace("-", "") == b
+
+
+def test_aligner_known_answers(O):
+    """Math-pinned cases: any correct affine NW (11/1, BLOSUM62) must return these."""
+    s = "MKTAYIAKQRQISFVKSHFSRQLEERLGLIEVQ"
+    tb = O.nw_traceback(s, s)
+    assert tb.comp == "|" * len(s) and tb.score == sum(O.lib().pco_blosum62(O.lib().pco_map(ord(c)), O.lib().pco_map(ord(c))) for c in s)
+    # one substitution: (L-1)/L identity, no gaps
+    t = s[:10] + "W" + s[11:]
+    tb = O.nw_traceback(s, t)
+    assert "-" not in tb.query + tb.ref and tb.comp.count("|") == len(s) - 1
+    # a clean internal deletion of 3 residues in a long, otherwise identical pair: one gap run of 3
+    long = (s * 3)
+    cut = long[:40] + long[43:]
+    tb = O.nw_traceback(long, cut)
+    assert tb.ref.count("-") == 3 and tb.query.count("-") == 0 and "---" in tb.ref
+    assert tb.comp.count("|") == len(cut)
+    # single residues
+    assert O.nw_stats("M", "M") == (5, 1, 1)
+    assert O.nw_stats("M", "W")[1:] == (0, 1)
+    # case-insensitive identity, non-alphabet bytes score as '*' but only equal bytes are identical
+    assert O.nw_stats("mkv", "MKV")[1] == 3
+    assert O.nw_stats("J", "O") == (1, 0, 1) and O.nw_stats("J", "J") == (1, 1, 1)
+    # boundary gaps cost open + (k-1)*extend: "A" vs "AAAA" -> 4 - (11 + 2)
+    assert O.nw_stats("A", "AAAA")[0] == 4 - 13
+
+
+def test_unique_optimum_by_brute_force(O):
+    """Short pairs whose optimal alignment is provably unique (exhaustive enumeration):
+    tie-breaking cannot matter, so these pin the aligner independently of parasail."""
+    L = O.lib()
+
+    def score(x, y):
+        return L.pco_blosum62(L.pco_map(ord(x)), L.pco_map(ord(y)))
+
+    def enumerate_alignments(a, b):
+        # all (ops) sequences over {M, I(gap in a), D(gap in b)}
+        out = []
+
+        def rec(i, j, ops):
+            if i == len(a) and j == len(b):
+                out.append("".join(ops)); return
+            if i < len(a) and j < len(b):
+                rec(i + 1, j + 1, ops + ["M"])
+            if j < len(b):
+                rec(i, j + 1, ops + ["I"])
+            if i < len(a):
+                rec(i + 1, j, ops + ["D"])
+        rec(0, 0, [])
+        return out
+
+    def ops_score(a, b, ops):
+        i = j = 0; tot = 0; prev = None
+        for op in ops:
+            if op == "M":
+                tot += score(a[i], b[j]); i += 1; j += 1
+            else:
+                tot -= 1 if prev == op else 11
+                if op == "I": j += 1
+                else: i += 1
+            prev = op
+        return tot
+
+    rng = random.Random(4)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    checked = 0
+    for _ in range(300):
+        a = "".join(rng.choice(aa) for _ in range(rng.randint(1, 6)))
+        b = "".join(rng.choice(aa) for _ in range(rng.randint(1, 6)))
+        scored = sorted(((ops_score(a, b, ops), ops) for ops in enumerate_alignments(a, b)), reverse=True)
+        if len(scored) > 1 and scored[0][0] == scored[1][0]:
+            continue                                   # co-optimal: not a pinned case
+        best, ops = scored[0]
+        sc, ident, diag = O.nw_stats(a, b)
+        assert sc == best and diag == ops.count("M")
+        i = j = 0; want_ident = 0
+        for op in ops:
+            if op == "M":
+                want_ident += a[i] == b[j]; i += 1; j += 1
+            elif op == "I": j += 1
+            else: i += 1
+        assert ident == want_ident
+        checked += 1
+    assert checked > 100
+
+
+def test_round6_is_python_round(O):
+    rng = random.Random(2)
+    xs = [rng.random() for _ in range(50000)]
+    xs += [(rng.randint(0, 999999) + 0.5) / 1e6 for _ in range(50000)]
+    xs += [rng.randint(0, 2 ** 20) / 2 ** rng.randint(1, 24) % 1.0 for _ in range(50000)]
+    xs += [rng.randint(0, 300) / rng.randint(301, 700) for _ in range(50000)]
+    xs += [0.0, 1.0, 0.5, 1 / 128, 3 / 128, 1 / 640, 5e-7, 4.9999999e-7, 1e-300, 0.9999995]
+    for x in xs:
+        assert O.round6(x) == round(x, 6), x
+
+
+def test_synth_c_vs_python_restatement(O):
+    """Packed closed forms (C) == per-pair dict/set semantics (Python) on synthetic genomes."""
+    from phamclust_amd import build
+    build.build_synth()
+    from phamclust_amd.pack import unpack_genomes
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(14, 300, seed=5)
+    genomes = unpack_genomes(packed)
+    n = len(genomes)
+    for metric in ALL_METRICS:
+        for as_distance in (True, False):
+            want = [O.PY_METRICS[metric](genomes[i], genomes[j], as_distance=as_distance)
+                    for i in range(n) for j in range(i + 1, n)]
+            assert np.array_equal(O.fill(packed, metric, as_distance=as_distance), np.array(want))
+
+
+def test_fill_rows_is_a_prefix(O, small_packed):
+    full = O.fill(small_packed, "peq")
+    part, n_aln, n_cells = O.fill_rows(small_packed, "peq", 0, 5)
+    n = small_packed.n_genomes
+    k = sum(n - 1 - s for s in range(5))
+    assert np.array_equal(part[:k], full[:k]) and n_aln > 0 and n_cells > n_aln
