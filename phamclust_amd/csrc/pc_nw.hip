@@ -125,34 +125,110 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 //
 // One wave per task.  The task's column sequence b (lb residues) is cut into strips of W
 // columns, one strip per lane; G = ceil(lb/W) consecutive lanes form a segment, and
-// nseg = floor(64/G) segments of the same b work side by side on different row
+// nseg = min(16, floor(64/G)) segments of the same b work side by side on different row
 // sequences.  Lane k of a segment keeps the previous row of its W columns (Ho, F and the
 // two stats) in registers and at step t processes row t-k of the segment's row stream:
 // what it needs from the left neighbour -- Ho, E, stats of that lane's last column, and
 // the row's residue -- arrives by DPP wave_shr:1 from the neighbour's previous step, so
-// the active cells at any step form an anti-diagonal and no LDS or barrier is involved in
-// the recurrence.  The head lane of a segment feeds the stream: for every alignment a
-// "virtual row -1" (flag RESET: previous row := -inf, which makes the ordinary recurrence
-// produce the boundary H(-1,j) = -(11+j) with zero stats) followed by its la rows, back
-// to back, so the pipeline fills once per task, not once per alignment.  The lane holding
-// column lb-1 emits (n_ident, aln_len) when a row flagged LAST leaves it.
-// Substitution scores come from a per-task profile in LDS: prof[r][k][c] = S(r, b_j)+11,
-// one ds_read of W bytes per lane per row.
+// the active cells at any step form an anti-diagonal and neither LDS nor a barrier is
+// involved in the recurrence.  A segment's stream is its row sequences back to back, each
+// preceded by a "virtual row -1" (flag RESET: previous row := -inf, which makes the
+// ordinary recurrence produce the boundary H(-1,j) = -(11+j) with zero stats), so the
+// pipeline fills once per task, not once per alignment.  The stream is staged through LDS
+// 32 entries at a time (coalesced residue reads); the head lane of a segment only reads
+// one 16-bit entry per step.  The lane holding column lb-1 emits (n_ident, aln_len) when a
+// row flagged LAST leaves it.  Substitution scores come from a per-task profile in LDS:
+// prof[r][k][c] = S(r, b_j)+11, one ds_read of W bytes per lane per row.
+//
+// The DP cell is hand-scheduled (pc_cell_asm): 17 VALU instructions, column state updated
+// in place, the NEXT cell's diagonal term computed from the old column state before it is
+// overwritten (so no register copies), and every VALU-written SGPR pair read >= 2
+// instructions later (gfx950 needs 2 wait states there; hipcc pads nothing inside asm).
 // ---------------------------------------------------------------------------------
 #define PCF_RESET 0x100
 #define PCF_LAST 0x200
+#define PC_MAX_SEG 16
+#define PC_WIN 32                                   // stream entries staged per refill
 
 __device__ __forceinline__ int pc_shr1(int v) {                        // lane k <- lane k-1 (lane 0 keeps 0)
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);  // DPP wave_shr:1
 }
+
+// One cell.  In: D, SD (this cell's diagonal candidates), chain (Hol, El, SHl, SEl), row code ac.
+// In/out (in place): column state Hou -> Ho, Fu -> F, SHu -> SH, SFu -> SF.
+// Out: E, SE (chain), and for the next cell Dn = old Hou + sp_next, SDn = old SHu + 0x10000 + (ac == bcn).
+#define PC_CELL_BODY(SDWA_NEXT, NEXT_LINES)                                                     \
+    asm volatile(                                                                               \
+        "v_add_u32 %[Ee], -1, %[El]\n\t"                                                        \
+        "v_add_u32 %[Fe], -1, %[Fu]\n\t"                                                        \
+        "v_cmp_gt_i32 %[c0], %[Hol], %[Ee]\n\t"                                                 \
+        "v_cmp_gt_i32 %[c1], %[Hou], %[Fe]\n\t"                                                 \
+        "v_cmp_eq_u32 %[c2], %[ac], %[bcn]\n\t"                                                 \
+        "v_max_i32 %[E], %[Hol], %[Ee]\n\t"                                                     \
+        "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
+        "v_max_i32 %[Fu], %[Hou], %[Fe]\n\t"                                                    \
+        "v_cndmask_b32 %[SFu], %[SFu], %[SHu], %[c1]\n\t"                                       \
+        NEXT_LINES                                                                              \
+        "v_max3_i32 %[H], %[D], %[E], %[Fu]\n\t"                                                \
+        "v_cmp_eq_u32 %[c3], %[H], %[Fu]\n\t"                                                   \
+        "v_cmp_eq_u32 %[c4], %[H], %[D]\n\t"                                                    \
+        "v_add_u32 %[Hou], -11, %[H]\n\t"                                                       \
+        "v_cndmask_b32 %[T], %[SE], %[SFu], %[c3]\n\t"                                          \
+        "v_cndmask_b32 %[SHu], %[T], %[SD], %[c4]\n\t"                                          \
+        : [Ee] "=&v"(Ee), [Fe] "=&v"(Fe), [E] "=&v"(E), [SE] "=&v"(SE), [H] "=&v"(H), [T] "=&v"(T),              \
+          [Dn] "=&v"(Dn), [SDn] "=&v"(SDn), [Hou] "+v"(Hou), [Fu] "+v"(Fu), [SHu] "+v"(SHu), [SFu] "+v"(SFu),    \
+          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4)                         \
+        : [D] "v"(D), [SD] "v"(SD), [Hol] "v"(Hol), [El] "v"(El), [SHl] "v"(SHl), [SEl] "v"(SEl), [ac] "v"(ac),  \
+          [bcn] "v"(bcn), [pwn] "v"(pwn), [K] "v"(K))
+
+#define PC_NEXT(SEL)                                                                             \
+    "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
+    "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
+
+template <int NEXT_BYTE>   // byte of pwn holding the next cell's score; -1: last cell of the lane
+__device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl,
+                                            int& Hou, int& Fu, uint32_t& SHu, uint32_t& SFu, int& E, uint32_t& SE,
+                                            int& Dn, uint32_t& SDn, int ac, int bcn, uint32_t pwn, uint32_t K) {
+    int Ee, Fe, H; uint32_t T;
+    unsigned long long c0, c1, c2, c3, c4;
+    if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(0, PC_NEXT("BYTE_0"));
+    else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(1, PC_NEXT("BYTE_1"));
+    else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(2, PC_NEXT("BYTE_2"));
+    else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(3, PC_NEXT("BYTE_3"));
+    else { PC_CELL_BODY(-1, ""); Dn = 0; SDn = 0; }
+}
+
+template <int W, int C>
+struct PcRow {          // compile-time unrolled sweep over the lane's W columns
+    static __device__ __forceinline__ void run(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl, int (&Hou)[W],
+                                               int (&Fu)[W], uint32_t (&SHu)[W], uint32_t (&SFu)[W], const int (&bc)[W],
+                                               const uint32_t (&pw)[(W + 3) / 4], int ac, uint32_t K, int& E_out, uint32_t& SE_out) {
+        int E, Dn; uint32_t SE, SDn;
+        constexpr int NB = (C + 1 < W) ? ((C + 1) & 3) : -1;
+        pc_cell_asm<NB>(D, SD, Hol, El, SHl, SEl, Hou[C], Fu[C], SHu[C], SFu[C], E, SE, Dn, SDn, ac,
+                        bc[(C + 1 < W) ? C + 1 : C], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
+        if constexpr (C + 1 < W)
+            PcRow<W, C + 1>::run(Dn, SDn, Hou[C], E, SHu[C], SE, Hou, Fu, SHu, SFu, bc, pw, ac, K, E_out, SE_out);
+        else { E_out = E; SE_out = SE; }
+    }
+};
 
 template <int W>
 __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                     const int32_t* __restrict__ bucket_row,
                                                     const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res) {
     constexpr int ND = (W + 3) / 4;                 // profile dwords per lane per residue row
-    extern __shared__ uint32_t prof[];              // [24][G][ND]
-    __shared__ int8_t tab[24][24];
+    // one dynamic LDS array (16-byte aligned); fixed part first, profile last
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    int8_t (*tab)[24] = (int8_t(*)[24])smem;                         // [24][24]            576 B
+    uint32_t* row_la = smem + 144;                                   // [64] rows of the task: length
+    uint32_t* row_pos = row_la + 64;                                 // [64] start of the row's record in its segment's stream
+    uint32_t* row_lo = row_pos + 64;                                 // [64] code offset, low / high dword
+    uint32_t* row_hi = row_lo + 64;
+    uint32_t* seg_len = row_hi + 64;                                 // [16] stream length per segment
+    uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] task row whose record holds the window start
+    uint16_t* ring = (uint16_t*)(seg_cur + PC_MAX_SEG);              // [16][PC_WIN] staged stream entries
+    uint32_t* prof = (uint32_t*)(ring + PC_MAX_SEG * PC_WIN);        // [24][G][ND]
     const int lane = threadIdx.x;
     for (int i = lane; i < 576; i += 64) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
 
@@ -160,17 +236,30 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
     const int lb = d.gene_len[tk.gene];
     const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
     const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
-    const int nseg = 64 / G;
+    const int nseg = min(64 / G, PC_MAX_SEG);
     const int seg = lane / G, k = lane - seg * G;
     const bool in_seg = seg < nseg;
     const bool is_head = in_seg && k == 0;
     const int k_out = (lb - 1) / W, c_out = (lb - 1) - k_out * W;
     const bool is_out = in_seg && k == k_out;
+    const int R = tk.end - tk.begin;                // rows (alignments) of this task, <= 64
 
     int bc[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) { const int j = k * W + c; bc[c] = (in_seg && j < lb) ? (int)bp[j] : PC_PADCODE; }
+    if (lane < R) {
+        const int ga = bucket_row[tk.begin + lane];
+        const unsigned long long off = (unsigned long long)d.gene_off[ga];
+        row_la[lane] = (uint32_t)d.gene_len[ga]; row_lo[lane] = (uint32_t)off; row_hi[lane] = (uint32_t)(off >> 32);
+    }
     __syncthreads();
+    if (lane < R) {                                  // record start = sum of (la+1) of the earlier rows of my segment
+        uint32_t acc = 0;
+        for (int q = lane % nseg; q < lane; q += nseg) acc += row_la[q] + 1;
+        row_pos[lane] = acc;
+        if (lane + nseg >= R) seg_len[lane % nseg] = acc + row_la[lane] + 1;
+    }
+    if (lane < PC_MAX_SEG) { seg_cur[lane] = lane; if (lane >= R) seg_len[lane] = 0; }
     if (seg == 0) {                                  // segment 0 writes the shared profile
 #pragma unroll 1
         for (int r = 0; r < 24; ++r) {
@@ -187,87 +276,83 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
         }
     }
     __syncthreads();
-
-    // ---- head-lane stream state ---------------------------------------------------
-    int h_row = tk.begin + seg;                      // bucket row of the current alignment
-    int h_la = 0, h_i = -1;                          // rows, next row to emit (-1 = virtual row)
-    const uint8_t* h_ptr = d.codes;
-    int n_la = 0; const uint8_t* n_ptr = d.codes;    // prefetched next alignment
-    bool h_live = false;
     int T = 0;
-    if (is_head) {
-        int L = 0;
-        for (int r = h_row; r < tk.end; r += nseg) L += d.gene_len[bucket_row[r]] + 1;
-        T = L;
-        if (h_row < tk.end) {
-            const int ga = bucket_row[h_row]; h_la = d.gene_len[ga]; h_ptr = d.codes + d.gene_off[ga]; h_live = true;
-            if (h_row + nseg < tk.end) { const int gn = bucket_row[h_row + nseg]; n_la = d.gene_len[gn]; n_ptr = d.codes + d.gene_off[gn]; }
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) T = max(T, __shfl_xor(T, o));
+    for (int s2 = 0; s2 < nseg; ++s2) T = max(T, (int)seg_len[s2]);
     T += G - 1;
-    int out_row = tk.begin + seg;                    // out lane: bucket row of the next result
 
     int Hou[W], Fu[W]; uint32_t SHu[W], SFu[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; SHu[c] = 0; SFu[c] = 0; }
-    int o_a = 0, o_Ho = 0, o_E = PC_NEG; uint32_t o_SH = 0, o_SE = 0;   // my last column, previous step
-    int p_Hol = PC_NEG; uint32_t p_SHl = 0;                              // what I received last step (diag of slot 0)
-    int a_nxt = 0;                                                        // head: residue byte loaded one step ahead
-    if (is_head && h_live) a_nxt = h_ptr[0];
+    int o_a = 0, o_E = PC_NEG; uint32_t o_SE = 0;   // my last column's E/SE and the row code, previous step
+    int p_Hol = PC_NEG; uint32_t p_SHl = 0;         // what I received last step (diagonal of column 0)
+    int h_i = 0;                                     // head: index of the row being emitted
+    int out_r = seg;                                 // out lane: task row of the next result
+    const uint32_t K = 0x10000u;
+    const int half = lane >> 5, hl = lane & 31;
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        int a = pc_shr1(o_a);
-        int Hol = pc_shr1(o_Ho);
-        int El = pc_shr1(o_E);
-        uint32_t SHl = (uint32_t)pc_shr1((int)o_SH);
-        uint32_t SEl = (uint32_t)pc_shr1((int)o_SE);
-        if (is_head) {
-            El = PC_NEG; SHl = 0; SEl = 0;
-            if (!h_live) { a = 0; Hol = 0; }
-            else if (h_i < 0) { a = PCF_RESET; Hol = -PC_OPEN; h_i = 0; }                    // H(-1,-1) = 0
-            else {
-                a = a_nxt | (h_i == h_la - 1 ? PCF_LAST : 0);
-                Hol = -(PC_OPEN + h_i * PC_EXT) - PC_OPEN;                                    // H(i,-1)
-                ++h_i;
-                if (h_i == h_la) {                                                           // advance to the next alignment
-                    h_row += nseg; h_i = -1; h_la = n_la; h_ptr = n_ptr; h_live = h_row < tk.end;
-                    if (h_row + nseg < tk.end) { const int gn = bucket_row[h_row + nseg]; n_la = d.gene_len[gn]; n_ptr = d.codes + d.gene_off[gn]; }
+        if ((t & (PC_WIN - 1)) == 0) {
+            // ---- stage the next PC_WIN stream entries of every segment (two segments per pass) ----
+            __syncthreads();
+            for (int s0 = 0; s0 < nseg; s0 += 2) {
+                const int sg = s0 + half;
+                uint32_t entry = 0;
+                if (sg < nseg) {
+                    const uint32_t p = (uint32_t)t + hl;
+                    if (p < seg_len[sg]) {
+                        int r = (int)seg_cur[sg];
+                        while (p >= row_pos[r] + row_la[r] + 1) r += nseg;
+                        const int i = (int)(p - row_pos[r]) - 1;
+                        if (i < 0) entry = PCF_RESET;
+                        else {
+                            const uint8_t* ap = d.codes + (((unsigned long long)row_hi[r] << 32) | row_lo[r]);
+                            entry = (uint32_t)ap[i] | (i == (int)row_la[r] - 1 ? PCF_LAST : 0);
+                        }
+                        if (hl == PC_WIN - 1) seg_cur[sg] = (uint32_t)r;
+                    }
+                    ring[sg * PC_WIN + hl] = (uint16_t)entry;
                 }
             }
-            if (h_live) a_nxt = h_ptr[h_i < 0 ? 0 : h_i];                                   // prefetch for the next step
+            __syncthreads();
+        }
+        asm volatile("s_nop 1" ::: "memory");        // VALU (asm, previous step) -> DPP read: 2 wait states
+        int a = pc_shr1(o_a);
+        int Hol = pc_shr1(Hou[W - 1]);
+        int El = pc_shr1(o_E);
+        uint32_t SHl = (uint32_t)pc_shr1((int)SHu[W - 1]);
+        uint32_t SEl = (uint32_t)pc_shr1((int)o_SE);
+        {   // head lanes take the staged stream entry and the left boundary instead
+            const int e = in_seg ? (int)ring[seg * PC_WIN + (t & (PC_WIN - 1))] : 0;
+            const bool rst = (e & PCF_RESET) != 0;
+            h_i = rst ? -1 : h_i + 1;                                  // row index of this entry
+            const int hb = rst ? -PC_OPEN : -(2 * PC_OPEN) - h_i * PC_EXT;   // H(i,-1) - 11; virtual row: H(-1,-1) - 11
+            a = is_head ? e : a; Hol = is_head ? hb : Hol; El = is_head ? PC_NEG : El;
+            SHl = is_head ? 0u : SHl; SEl = is_head ? 0u : SEl;
         }
         int Hod = p_Hol; uint32_t SHd = p_SHl;
         p_Hol = Hol; p_SHl = SHl;
-        if (a & PCF_RESET) {
+        if (__builtin_amdgcn_ballot_w64((a & PCF_RESET) != 0) != 0) {     // some lane starts an alignment this step
+            const bool rst = (a & PCF_RESET) != 0;
 #pragma unroll
-            for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; }
-            Hod = PC_NEG;
+            for (int c = 0; c < W; ++c) { Hou[c] = rst ? PC_NEG : Hou[c]; Fu[c] = rst ? PC_NEG : Fu[c]; }
+            Hod = rst ? PC_NEG : Hod;
         }
         const int ac = a & 0xff;
         const uint32_t* pr = prof + (min(ac, 23) * G + k) * ND;
         uint32_t pw[ND];
 #pragma unroll
         for (int q = 0; q < ND; ++q) pw[q] = pr[q];
-        int E_last = PC_NEG; uint32_t SE_last = 0;
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-            const int sp = (int)((pw[c >> 2] >> (8 * (c & 3))) & 0xffu);
-            const PcCell x = pc_cell(Hol, El, SHl, SEl, Hou[c], Fu[c], SHu[c], SFu[c], Hod, SHd, sp, ac == bc[c]);
-            Hod = Hou[c]; SHd = SHu[c];
-            Hou[c] = x.Ho; Fu[c] = x.F; SHu[c] = x.SH; SFu[c] = x.SF;
-            Hol = x.Ho; El = x.E; SHl = x.SH; SEl = x.SE;
-            E_last = x.E; SE_last = x.SE;
-        }
-        o_a = a; o_Ho = Hol; o_E = E_last; o_SH = SHl; o_SE = SE_last;
+        const int D0 = Hod + (int)(pw[0] & 0xffu);
+        const uint32_t SD0 = SHd + K + (ac == bc[0] ? 1u : 0u);
+        PcRow<W, 0>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, ac, K, o_E, o_SE);
+        o_a = a;
         if ((a & PCF_LAST) && is_out) {
             uint32_t st = SHu[0];
 #pragma unroll
             for (int c = 1; c < W; ++c) if (c == c_out) st = SHu[c];
-            const int la = d.gene_len[bucket_row[out_row]];
-            res[bucket_dest[out_row]] = make_uint2(st & 0xffffu, (uint32_t)(la + lb) - (st >> 16));
-            out_row += nseg;
+            res[bucket_dest[tk.begin + out_r]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
+            out_r += nseg;
         }
     }
 }
@@ -300,7 +385,7 @@ static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, cons
                            const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
     const int ND = (W + 3) / 4;
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
-    const size_t lds = (size_t)24 * Gmax * ND * 4;
+    const size_t lds = (size_t)(144 + 4 * 64 + 2 * PC_MAX_SEG) * 4 + (size_t)PC_MAX_SEG * PC_WIN * 2 + (size_t)24 * Gmax * ND * 4;
     hipLaunchKernelGGL(k_nw_systolic<W>, dim3((unsigned)ntasks), dim3(64), lds, st, d, tasks, bucket_row, bucket_dest, res);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d> launch: %s", W, hipGetErrorString(e)); return PC_ERR_HIP; }

@@ -74,6 +74,37 @@ def test_align_pairs_integer_outputs(gpu_ctx, native_built, variant):
     assert np.array_equal(diag, want_d)
 
 
+@pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20])
+def test_every_systolic_variant(gpu_ctx, native_built, w):
+    """Each compiled columns-per-lane variant, forced, on column genes from 1 residue up to its
+    64*w limit, many rows per column gene (streams of back-to-back alignments, several segments)."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(100 + w)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    cap = min(64 * w, 900)
+    lens = sorted(set([1, 2, w, w + 1, 2 * w - 1, 16 * w, 16 * w + 1, 21 * w, 32 * w, 32 * w + 1, cap - 1, cap]
+                      + rng.integers(1, cap + 1, 6).tolist()))
+    lens = [x for x in lens if 1 <= x <= cap]
+    g = Genome("cols")
+    for i, ln in enumerate(lens):
+        g.add(f"c{i:02d}", "".join(aa[rng.integers(0, 20, ln)]))
+    h = Genome("rows")
+    for i in range(40):
+        base = g.phams[f"c{i % len(lens):02d}"][0]
+        cut = rng.integers(0, max(1, len(base)))
+        h.add(f"r{i:02d}", (base[:cut] + "".join(aa[rng.integers(0, 20, rng.integers(0, 4))]) + base[cut + rng.integers(0, 3):]) or "M")
+    pk = pack_genomes([g, h])
+    ncol = len(lens)
+    a = np.repeat(np.arange(ncol, ncol + 40, dtype=np.int32), ncol)      # rows: genes of "rows"
+    b = np.tile(np.arange(ncol, dtype=np.int32), 40)                      # cols: genes of "cols"
+    gpu_ctx.upload(pk)
+    ident, diag = gpu_ctx.align_pairs(a, b, variant=w)
+    _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+    assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
+
+
 def test_round6_matches_python(gpu_ctx):
     rng = np.random.default_rng(9)
     xs = np.concatenate([
