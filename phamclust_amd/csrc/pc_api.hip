@@ -130,6 +130,15 @@ static void build_code_lut(uint8_t lut[256]) {
     for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)assigned[i];
 }
 
+// launch class of a column gene: variant * 4 + bucket of lanes per segment (<=8, <=16, <=32, <=64)
+static int pc_class_of(int lb, int variant) {
+    const int nvar = pc_nw_num_variants();
+    if (variant < 0) return nvar * 4;
+    const int W = pc_nw_variant_w(variant);
+    const int Gs = (lb + W - 1) / W;
+    return variant * 4 + (Gs <= 8 ? 0 : Gs <= 16 ? 1 : Gs <= 32 ? 2 : 3);
+}
+
 static int apply_shard(pc_ctx* c, int rank, int world) {
     const int N = c->dev.N;
     std::vector<int32_t> owned; std::vector<int64_t> lbase;
@@ -218,23 +227,24 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
         for (int i = 0; i < gene_len[k]; ++i) dst[i] = lut[src[i]];
     }
-    // class order: genes grouped by the kernel variant that will align against them as columns
+    // class order: genes grouped by the kernel variant that will align against them as columns, and by
+    // lanes-per-segment bucket (the profile's LDS footprint scales with it, and LDS sets occupancy)
     const int nvar = pc_nw_num_variants();
+    const int ncls_all = nvar * 4 + 1;                 // last class: general kernel
     std::vector<int> gene_cls(G);
-    std::vector<int64_t> cls_count(nvar + 1, 0);
-    std::vector<int> cls_maxlb(nvar + 1, 0);
+    std::vector<int64_t> cls_count(ncls_all, 0);
+    std::vector<int> cls_maxlb(ncls_all, 0);
     for (int k = 0; k < G; ++k) {
-        int v = pc_nw_choose_variant(gene_len[k]);
-        int cls = v < 0 ? nvar : v;
+        const int cls = pc_class_of(gene_len[k], pc_nw_choose_variant(gene_len[k]));
         gene_cls[k] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], gene_len[k]);
     }
     c->cls_variant.clear(); c->cls_begin.clear(); c->cls_max_lb.clear();
-    std::vector<int64_t> cls_pos(nvar + 1, 0);
+    std::vector<int64_t> cls_pos(ncls_all, 0);
     {
         int64_t run = 0;
-        for (int cls = 0; cls <= nvar; ++cls) {
+        for (int cls = 0; cls < ncls_all; ++cls) {
             cls_pos[cls] = run;
-            if (cls_count[cls]) { c->cls_variant.push_back(cls == nvar ? -1 : cls); c->cls_begin.push_back((int32_t)run); c->cls_max_lb.push_back(cls_maxlb[cls]); }
+            if (cls_count[cls]) { c->cls_variant.push_back(cls == ncls_all - 1 ? -1 : cls / 4); c->cls_begin.push_back((int32_t)run); c->cls_max_lb.push_back(cls_maxlb[cls]); }
             run += cls_count[cls];
         }
         c->cls_begin.push_back((int32_t)run);
@@ -447,7 +457,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         if (la == 0 || lb == 0) { pc_set_error("pc_align_pairs: empty translation at %lld", (long long)k); return PC_ERR_DATA; }
         int v = forced == -2 ? pc_nw_choose_variant(lb) : forced;
         if (v >= 0 && lb > 64 * pc_nw_variant_w(v)) { pc_set_error("pc_align_pairs: column gene of %d residues does not fit variant w=%d", lb, pc_nw_variant_w(v)); return PC_ERR_ARG; }
-        cls[k] = v < 0 ? nvar : v;
+        cls[k] = pc_class_of(lb, v);
         sums[k] = la + lb;
     }
     std::vector<int64_t> order(n);
@@ -458,8 +468,9 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         return x < y;
     });
     std::vector<int32_t> rows(n); std::vector<uint32_t> dest(n); std::vector<PcTask> tasks;
-    std::vector<uint32_t> cls_task_begin(nvar + 2, 0);
-    std::vector<int> cls_maxlb(nvar + 1, 0);
+    const int ncls_all = nvar * 4 + 1;
+    std::vector<uint32_t> cls_task_begin(ncls_all + 1, 0);
+    std::vector<int> cls_maxlb(ncls_all, 0);
     {
         int cur_cls = -1;
         for (int64_t i = 0; i < n;) {
@@ -475,18 +486,18 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
             for (int64_t r = i; r < j; ++r) { rows[r] = a_gene[order[r]]; dest[r] = (uint32_t)order[r]; }
             i = j;
         }
-        while (cur_cls < nvar + 1) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
+        while (cur_cls < ncls_all) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
     }
     DevBuf d_sums, d_ident, d_diag;
     hipStream_t st = c->stream;
     auto cleanup = [&]() { d_sums.release(); d_ident.release(); d_diag.release(); };
     if ((rc = upload_vec(c->b_bucket_row, rows)) || (rc = upload_vec(c->b_bucket_dest, dest)) || (rc = upload_vec(c->b_tasks, tasks)) ||
         (rc = c->b_res.ensure(n * 8)) || (rc = upload_vec(d_sums, sums)) || (rc = d_ident.ensure(n * 4)) || (rc = d_diag.ensure(n * 4))) { cleanup(); return rc; }
-    for (int cl = 0; cl <= nvar; ++cl) {
+    for (int cl = 0; cl < ncls_all; ++cl) {
         const int nt = (int)(cls_task_begin[cl + 1] - cls_task_begin[cl]);
         if (nt <= 0) continue;
         void* scratch = nullptr; size_t sbytes = 0;
-        const int v = cl == nvar ? -1 : cl;
+        const int v = cl == ncls_all - 1 ? -1 : cl / 4;
         if (v < 0) {
             sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[cl]);
             if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return rc; }
