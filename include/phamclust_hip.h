@@ -133,6 +133,9 @@ int pc_assemble_dev(pc_ctx* ctx, const void* gathered_dev, int world, void* out_
 int pc_align_pairs(pc_ctx* ctx, const int32_t* a_gene, const int32_t* b_gene, int64_t n, int variant,
                    int32_t* n_ident, int32_t* n_diag);
 
+/* Test / tuning hook: HIP-event milliseconds of the alignment kernels of the last pc_align_pairs call. */
+float pc_last_align_ms(const pc_ctx* ctx);
+
 /* Test hook: the device implementation of Python's round(x, 6) (the rounding every metric
  * returns through, e.g. metrics.py:50-53) applied to n host doubles in [0, 2^20). */
 int pc_round6_probe(pc_ctx* ctx, const double* in, double* out, int64_t n);

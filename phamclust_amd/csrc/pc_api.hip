@@ -75,6 +75,7 @@ struct pc_ctx {
     DevBuf b_na, b_off, b_col_cnt, b_col_start, b_col_cur, b_cnt_q, b_start_q, b_ntask_q, b_task_off_q, b_scan_tmp;
     DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
+    float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -493,6 +494,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
     auto cleanup = [&]() { d_sums.release(); d_ident.release(); d_diag.release(); };
     if ((rc = upload_vec(c->b_bucket_row, rows)) || (rc = upload_vec(c->b_bucket_dest, dest)) || (rc = upload_vec(c->b_tasks, tasks)) ||
         (rc = c->b_res.ensure(n * 8)) || (rc = upload_vec(d_sums, sums)) || (rc = d_ident.ensure(n * 4)) || (rc = d_diag.ensure(n * 4))) { cleanup(); return rc; }
+    (void)hipEventRecord(c->ev[1], st);
     for (int cl = 0; cl < ncls_all; ++cl) {
         const int nt = (int)(cls_task_begin[cl + 1] - cls_task_begin[cl]);
         if (nt <= 0) continue;
@@ -507,16 +509,20 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
                           c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], st);
         if (rc != PC_OK) { cleanup(); return rc; }
     }
+    (void)hipEventRecord(c->ev[2], st);
     rc = pc_launch_unpack_res(c->b_res.as<uint2>(), d_sums.as<int32_t>(), d_ident.as<int32_t>(), d_diag.as<int32_t>(), n, st);
     if (rc == PC_OK) {
         hipError_t e = hipMemcpyAsync(n_ident, d_ident.p, n * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(n_diag, d_diag.p, n * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipEventElapsedTime(&c->last_align_ms, c->ev[1], c->ev[2]);
         if (e != hipSuccess) { pc_set_error("pc_align_pairs: %s", hipGetErrorString(e)); rc = PC_ERR_HIP; }
     }
     cleanup();
     return rc;
 }
+
+extern "C" float pc_last_align_ms(const pc_ctx* c) { return c ? c->last_align_ms : -1.f; }
 
 // test hook for the device round(x, 6)
 extern "C" int pc_round6_probe(pc_ctx* c, const double* in, double* out, int64_t n) {

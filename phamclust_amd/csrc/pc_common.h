@@ -7,7 +7,7 @@
 #define PC_EXT 1              // gap extend
 #define PC_NEG (-(1 << 29))   // "-infinity" that survives a few subtractions without wrapping
 #define PC_PADCODE 255        // residue code of padding: never equal to a real code
-#define PC_TASK_ROWS 64       // max alignments (row sequences) per wave task
+#define PC_TASK_ROWS 256      // max alignments (row sequences) per workgroup task (4 waves x 64)
 #define PC_MAX_W 20           // widest systolic variant: 64 lanes * 20 columns = 1280 columns
 
 // Device view of the uploaded genomes (all pointers are HBM).

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
         const PcTask tk = tasks[task];
         const int lb = d.gene_len[tk.gene];
         const uint8_t* bp = d.codes + d.gene_off[tk.gene];
-        const int row = tk.begin + lane;
+      for (int base = tk.begin; base < tk.end; base += 64) {       // a task may hold up to PC_TASK_ROWS rows
+        const int row = base + lane;
         const bool active = row < tk.end;
         int la = 0; const uint8_t* ap = nullptr;
         if (active) { const int ga = bucket_row[row]; la = d.gene_len[ga]; ap = d.codes + d.gene_off[ga]; }
@@ -117,16 +118,20 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
             const uint32_t ident = final_stat & 0xffffu, ndiag = final_stat >> 16;
             res[bucket_dest[row]] = make_uint2(ident, (uint32_t)(la + lb) - ndiag);
         }
+      }
     }
 }
 
 // ---------------------------------------------------------------------------------
 // Systolic kernel (the production path): wavefront-level anti-diagonal sweep.
 //
-// One wave per task.  The task's column sequence b (lb residues) is cut into strips of W
-// columns, one strip per lane; G = ceil(lb/W) consecutive lanes form a segment, and
-// nseg = min(16, floor(64/G)) segments of the same b work side by side on different row
-// sequences.  Lane k of a segment keeps the previous row of its W columns (Ho, F and the
+// One workgroup (4 waves) per task = one column gene + up to 256 of its row sequences; the
+// waves share the column gene's substitution profile in LDS (the profile is 24*lb bytes, so
+// sharing it is what keeps 4 waves per SIMD resident for long genes) and otherwise run
+// independently (one barrier, after the profile is built).  Within a wave the column
+// sequence b (lb residues) is cut into strips of W columns, one strip per lane; G = ceil(lb/W)
+// consecutive lanes form a segment, and nseg = min(16, floor(64/G)) segments of the same b
+// work side by side on different row sequences.  Lane k of a segment keeps the previous row of its W columns (Ho, F and the
 // two stats) in registers and at step t processes row t-k of the segment's row stream:
 // what it needs from the left neighbour -- Ho, E, stats of that lane's last column, and
 // the row's residue -- arrives by DPP wave_shr:1 from the neighbour's previous step, so
@@ -213,56 +218,57 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
     }
 };
 
+#define PC_WAVES 4                                  // waves per workgroup, sharing one profile
+#define PC_WREG (4 * 64 + 2 * PC_MAX_SEG + PC_MAX_SEG * PC_WIN / 2)   // u32 of private LDS per wave
+
+__device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read inside ONE wave (in-order LDS queue)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <int W>
-__global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
-                                                    const int32_t* __restrict__ bucket_row,
-                                                    const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res) {
+__global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+                                                               const int32_t* __restrict__ bucket_row,
+                                                               const uint32_t* __restrict__ bucket_dest,
+                                                               uint2* __restrict__ res) {
     constexpr int ND = (W + 3) / 4;                 // profile dwords per lane per residue row
-    // one dynamic LDS array (16-byte aligned); fixed part first, profile last
+    // one dynamic LDS array (16-byte aligned): score table | 4 private wave regions | shared profile
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
     int8_t (*tab)[24] = (int8_t(*)[24])smem;                         // [24][24]            576 B
-    uint32_t* row_la = smem + 144;                                   // [64] rows of the task: length
+    uint32_t* wreg = smem + 144 + wv * PC_WREG;
+    uint32_t* row_la = wreg;                                         // [64] this wave's rows: length
     uint32_t* row_pos = row_la + 64;                                 // [64] start of the row's record in its segment's stream
     uint32_t* row_lo = row_pos + 64;                                 // [64] code offset, low / high dword
     uint32_t* row_hi = row_lo + 64;
     uint32_t* seg_len = row_hi + 64;                                 // [16] stream length per segment
-    uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] task row whose record holds the window start
+    uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] local row whose record holds the window start
     uint16_t* ring = (uint16_t*)(seg_cur + PC_MAX_SEG);              // [16][PC_WIN] staged stream entries
-    uint32_t* prof = (uint32_t*)(ring + PC_MAX_SEG * PC_WIN);        // [24][G][ND]
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 576; i += 64) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
+    uint32_t* prof = smem + 144 + PC_WAVES * PC_WREG;                // [24][G][ND], shared by the 4 waves
+    for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
 
     const PcTask tk = tasks[blockIdx.x];
     const int lb = d.gene_len[tk.gene];
     const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
     const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
     const int nseg = min(64 / G, PC_MAX_SEG);
+    const int NS = PC_WAVES * nseg;                 // row slots of the workgroup
     const int seg = lane / G, k = lane - seg * G;
     const bool in_seg = seg < nseg;
     const bool is_head = in_seg && k == 0;
     const int k_out = (lb - 1) / W, c_out = (lb - 1) - k_out * W;
     const bool is_out = in_seg && k == k_out;
-    const int R = tk.end - tk.begin;                // rows (alignments) of this task, <= 64
+    const int R = tk.end - tk.begin;                // rows (alignments) of this workgroup task, <= 256
+    // wave-local row lr <-> task row (lr / nseg) * NS + wv * nseg + lr % nseg  (monotone in lr)
+    auto task_row = [&](int lr) { return (lr / nseg) * NS + wv * nseg + (lr % nseg); };
 
     int bc[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) { const int j = k * W + c; bc[c] = (in_seg && j < lb) ? (int)bp[j] : PC_PADCODE; }
-    if (lane < R) {
-        const int ga = bucket_row[tk.begin + lane];
-        const unsigned long long off = (unsigned long long)d.gene_off[ga];
-        row_la[lane] = (uint32_t)d.gene_len[ga]; row_lo[lane] = (uint32_t)off; row_hi[lane] = (uint32_t)(off >> 32);
-    }
-    __syncthreads();
-    if (lane < R) {                                  // record start = sum of (la+1) of the earlier rows of my segment
-        uint32_t acc = 0;
-        for (int q = lane % nseg; q < lane; q += nseg) acc += row_la[q] + 1;
-        row_pos[lane] = acc;
-        if (lane + nseg >= R) seg_len[lane % nseg] = acc + row_la[lane] + 1;
-    }
-    if (lane < PC_MAX_SEG) { seg_cur[lane] = lane; if (lane >= R) seg_len[lane] = 0; }
-    if (seg == 0) {                                  // segment 0 writes the shared profile
+    __syncthreads();                                 // score table visible
+    if (seg == 0) {                                  // each wave's segment-0 lanes write 6 of the 24 profile rows
 #pragma unroll 1
-        for (int r = 0; r < 24; ++r) {
+        for (int r = wv; r < 24; r += PC_WAVES) {
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
                 uint32_t v = 0;
@@ -275,10 +281,26 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
             }
         }
     }
-    __syncthreads();
+    const int my_r = task_row(lane);
+    const int Rw = __popcll(__builtin_amdgcn_ballot_w64(my_r < R));   // this wave's rows (a prefix of lr)
+    if (lane < Rw) {
+        const int ga = bucket_row[tk.begin + my_r];
+        const unsigned long long off = (unsigned long long)d.gene_off[ga];
+        row_la[lane] = (uint32_t)d.gene_len[ga]; row_lo[lane] = (uint32_t)off; row_hi[lane] = (uint32_t)(off >> 32);
+    }
+    __syncthreads();                                 // profile complete; the only workgroup barrier
+    if (Rw == 0) return;
+    if (lane < Rw) {                                 // record start = sum of (la+1) of the earlier rows of my segment
+        uint32_t acc = 0;
+        for (int q = lane % nseg; q < lane; q += nseg) acc += row_la[q] + 1;
+        row_pos[lane] = acc;
+        if (lane + nseg >= Rw) seg_len[lane % nseg] = acc + row_la[lane] + 1;
+    }
+    if (lane < PC_MAX_SEG) { seg_cur[lane] = lane; if (lane >= Rw) seg_len[lane] = 0; }
+    pc_wave_lds_sync();
     int T = 0;
     for (int s2 = 0; s2 < nseg; ++s2) T = max(T, (int)seg_len[s2]);
-    T += G - 1;
+    T = __builtin_amdgcn_readfirstlane(T) + G - 1;
 
     int Hou[W], Fu[W]; uint32_t SHu[W], SFu[W];
 #pragma unroll
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
     int o_a = 0, o_E = PC_NEG; uint32_t o_SE = 0;   // my last column's E/SE and the row code, previous step
     int p_Hol = PC_NEG; uint32_t p_SHl = 0;         // what I received last step (diagonal of column 0)
     int h_i = 0;                                     // head: index of the row being emitted
-    int out_r = seg;                                 // out lane: task row of the next result
+    int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
     const int half = lane >> 5, hl = lane & 31;
 
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
     for (int t = 0; t < T; ++t) {
         if ((t & (PC_WIN - 1)) == 0) {
             // ---- stage the next PC_WIN stream entries of every segment (two segments per pass) ----
-            __syncthreads();
+            pc_wave_lds_sync();
             for (int s0 = 0; s0 < nseg; s0 += 2) {
                 const int sg = s0 + half;
                 uint32_t entry = 0;
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
                     ring[sg * PC_WIN + hl] = (uint16_t)entry;
                 }
             }
-            __syncthreads();
+            pc_wave_lds_sync();
         }
         asm volatile("s_nop 1" ::: "memory");        // VALU (asm, previous step) -> DPP read: 2 wait states
         int a = pc_shr1(o_a);
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(64) void k_nw_systolic(PcDev d, const PcTask* __res
             uint32_t st = SHu[0];
 #pragma unroll
             for (int c = 1; c < W; ++c) if (c == c_out) st = SHu[c];
-            res[bucket_dest[tk.begin + out_r]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
+            res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
             out_r += nseg;
         }
     }
@@ -385,8 +407,8 @@ static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, cons
                            const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
     const int ND = (W + 3) / 4;
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
-    const size_t lds = (size_t)(144 + 4 * 64 + 2 * PC_MAX_SEG) * 4 + (size_t)PC_MAX_SEG * PC_WIN * 2 + (size_t)24 * Gmax * ND * 4;
-    hipLaunchKernelGGL(k_nw_systolic<W>, dim3((unsigned)ntasks), dim3(64), lds, st, d, tasks, bucket_row, bucket_dest, res);
+    const size_t lds = (size_t)(144 + PC_WAVES * PC_WREG) * 4 + (size_t)24 * Gmax * ND * 4;
+    hipLaunchKernelGGL(k_nw_systolic<W>, dim3((unsigned)ntasks), dim3(64 * PC_WAVES), lds, st, d, tasks, bucket_row, bucket_dest, res);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d> launch: %s", W, hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;

@@ -43,7 +43,7 @@ class PcStats(ctypes.Structure):
 
 EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
-           "pc_align_pairs", "pc_round6_probe"]
+           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe"]
 
 _lib = None
 
@@ -85,6 +85,8 @@ def load():
     L.pc_assemble_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     L.pc_align_pairs.argtypes = [vp, _i32p, _i32p, ctypes.c_int64, ctypes.c_int, _i32p, _i32p]
     L.pc_round6_probe.argtypes = [vp, _f64p, _f64p, ctypes.c_int64]
+    L.pc_last_align_ms.argtypes = [vp]
+    L.pc_last_align_ms.restype = ctypes.c_float
     _lib = L
     return L
 
@@ -187,6 +189,9 @@ class Context:
         self._check(self._lib.pc_align_pairs(self._h, _ptr(a, _i32p), _ptr(b, _i32p), n, int(variant),
                                              _ptr(ident, _i32p), _ptr(diag, _i32p)))
         return ident, diag
+
+    def last_align_ms(self):
+        return float(self._lib.pc_last_align_ms(self._h))
 
     def round6(self, values):
         v = np.ascontiguousarray(values, dtype=np.float64)
