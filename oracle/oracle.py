@@ -63,6 +63,7 @@ def lib():
         L.pco_fill.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int]
         L.pco_fill_rows.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     _f64p, ctypes.c_int, _i64p]
+        L.pco_pairs.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, _i32p, _i32p, ctypes.c_int64, _f64p, ctypes.c_int]
         L.pco_blosum62.argtypes = [ctypes.c_int, ctypes.c_int]
         L.pco_map.argtypes = [ctypes.c_int]
         _lib = L
@@ -139,6 +140,17 @@ def _struct(packed):
 
 def pair(packed, metric, s, t, as_distance=True):
     return lib().pco_pair(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), s, t)
+
+
+def pairs(packed, metric, s_idx, t_idx, as_distance=True, nthreads=0):
+    """Values of the listed pairs (s < t required, as in the matrix's upper triangle)."""
+    s_idx = np.ascontiguousarray(s_idx, dtype=np.int32)
+    t_idx = np.ascontiguousarray(t_idx, dtype=np.int32)
+    assert (s_idx < t_idx).all()
+    out = np.zeros(s_idx.shape[0], dtype=np.float64)
+    lib().pco_pairs(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), _ptr(s_idx, _i32p),
+                    _ptr(t_idx, _i32p), s_idx.shape[0], _ptr(out, _f64p), nthreads)
+    return out
 
 
 def fill(packed, metric, as_distance=True, nthreads=0):

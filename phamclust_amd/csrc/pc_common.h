@@ -7,7 +7,10 @@
 #define PC_EXT 1              // gap extend
 #define PC_NEG (-(1 << 29))   // "-infinity" that survives a few subtractions without wrapping
 #define PC_PADCODE 255        // residue code of padding: never equal to a real code
-#define PC_TASK_ROWS 256      // max alignments (row sequences) per workgroup task (4 waves x 64)
+// Max alignments (row sequences) per workgroup task.  A wave of the systolic kernel keeps at most 64
+// rows; rows are dealt to 4*nseg slots, so a wave receives ceil(R / (4 nseg)) * nseg of them: 208 is the
+// largest R for which that is <= 64 for every nseg in 1..16.
+#define PC_TASK_ROWS 208
 #define PC_MAX_W 20           // widest systolic variant: 64 lanes * 20 columns = 1280 columns
 
 // Device view of the uploaded genomes (all pointers are HBM).

@@ -145,7 +145,12 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 // row flagged LAST leaves it.  Substitution scores come from a per-task profile in LDS:
 // prof[r][k][c] = S(r, b_j)+11, one ds_read of W bytes per lane per row.
 //
-// The DP cell is hand-scheduled (pc_cell_asm): 17 VALU instructions, column state updated
+// Scores are kept with an anti-diagonal bias: every stored H, E, F of cell (i,j) carries
+// + (i + j).  Because the extend cost is exactly 1 per step, both extend decrements vanish:
+//   E^(i,j) = max(Ho^(i,j-1), E^(i,j-1)),  F^(i,j) = max(Ho^(i-1,j), F^(i-1,j)),  Ho^ = H^ - 10,
+//   H^(i,j) = max3(Ho^(i-1,j-1) + S + 12, E^, F^); all candidates of one cell share the bias, so every
+// comparison and tie-break is unchanged, and the boundaries become constants (Ho^(i,-1) = Ho^(-1,j) = -22,
+// Ho^(-1,-1) = -12).  The DP cell is hand-scheduled (pc_cell_asm): 15 VALU instructions, column state updated
 // in place, the NEXT cell's diagonal term computed from the old column state before it is
 // overwritten (so no register copies), and every VALU-written SGPR pair read >= 2
 // instructions later (gfx950 needs 2 wait states there; hipcc pads nothing inside asm).
@@ -164,23 +169,21 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
 // Out: E, SE (chain), and for the next cell Dn = old Hou + sp_next, SDn = old SHu + 0x10000 + (ac == bcn).
 #define PC_CELL_BODY(SDWA_NEXT, NEXT_LINES)                                                     \
     asm volatile(                                                                               \
-        "v_add_u32 %[Ee], -1, %[El]\n\t"                                                        \
-        "v_add_u32 %[Fe], -1, %[Fu]\n\t"                                                        \
-        "v_cmp_gt_i32 %[c0], %[Hol], %[Ee]\n\t"                                                 \
-        "v_cmp_gt_i32 %[c1], %[Hou], %[Fe]\n\t"                                                 \
+        "v_cmp_gt_i32 %[c0], %[Hol], %[El]\n\t"                                                 \
+        "v_cmp_gt_i32 %[c1], %[Hou], %[Fu]\n\t"                                                 \
         "v_cmp_eq_u32 %[c2], %[ac], %[bcn]\n\t"                                                 \
-        "v_max_i32 %[E], %[Hol], %[Ee]\n\t"                                                     \
+        "v_max_i32 %[E], %[Hol], %[El]\n\t"                                                     \
         "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
-        "v_max_i32 %[Fu], %[Hou], %[Fe]\n\t"                                                    \
+        "v_max_i32 %[Fu], %[Hou], %[Fu]\n\t"                                                    \
         "v_cndmask_b32 %[SFu], %[SFu], %[SHu], %[c1]\n\t"                                       \
         NEXT_LINES                                                                              \
         "v_max3_i32 %[H], %[D], %[E], %[Fu]\n\t"                                                \
         "v_cmp_eq_u32 %[c3], %[H], %[Fu]\n\t"                                                   \
         "v_cmp_eq_u32 %[c4], %[H], %[D]\n\t"                                                    \
-        "v_add_u32 %[Hou], -11, %[H]\n\t"                                                       \
+        "v_add_u32 %[Hou], -10, %[H]\n\t"                                                       \
         "v_cndmask_b32 %[T], %[SE], %[SFu], %[c3]\n\t"                                          \
         "v_cndmask_b32 %[SHu], %[T], %[SD], %[c4]\n\t"                                          \
-        : [Ee] "=&v"(Ee), [Fe] "=&v"(Fe), [E] "=&v"(E), [SE] "=&v"(SE), [H] "=&v"(H), [T] "=&v"(T),              \
+        : [E] "=&v"(E), [SE] "=&v"(SE), [H] "=&v"(H), [T] "=&v"(T),                                              \
           [Dn] "=&v"(Dn), [SDn] "=&v"(SDn), [Hou] "+v"(Hou), [Fu] "+v"(Fu), [SHu] "+v"(SHu), [SFu] "+v"(SFu),    \
           [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4)                         \
         : [D] "v"(D), [SD] "v"(SD), [Hol] "v"(Hol), [El] "v"(El), [SHl] "v"(SHl), [SEl] "v"(SEl), [ac] "v"(ac),  \
@@ -194,7 +197,7 @@ template <int NEXT_BYTE>   // byte of pwn holding the next cell's score; -1: las
 __device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl,
                                             int& Hou, int& Fu, uint32_t& SHu, uint32_t& SFu, int& E, uint32_t& SE,
                                             int& Dn, uint32_t& SDn, int ac, int bcn, uint32_t pwn, uint32_t K) {
-    int Ee, Fe, H; uint32_t T;
+    int H; uint32_t T;
     unsigned long long c0, c1, c2, c3, c4;
     if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(0, PC_NEXT("BYTE_0"));
     else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(1, PC_NEXT("BYTE_1"));
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] local row whose record holds the window start
     uint16_t* ring = (uint16_t*)(seg_cur + PC_MAX_SEG);              // [16][PC_WIN] staged stream entries
     uint32_t* prof = smem + 144 + PC_WAVES * PC_WREG;                // [24][G][ND], shared by the 4 waves
-    for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
+    for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + 12);   // S + 12: see the bias note
 
     const PcTask tk = tasks[blockIdx.x];
     const int lb = d.gene_len[tk.gene];
@@ -307,7 +310,6 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; SHu[c] = 0; SFu[c] = 0; }
     int o_a = 0, o_E = PC_NEG; uint32_t o_SE = 0;   // my last column's E/SE and the row code, previous step
     int p_Hol = PC_NEG; uint32_t p_SHl = 0;         // what I received last step (diagonal of column 0)
-    int h_i = 0;                                     // head: index of the row being emitted
     int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
     const int half = lane >> 5, hl = lane & 31;
@@ -346,9 +348,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
         uint32_t SEl = (uint32_t)pc_shr1((int)o_SE);
         {   // head lanes take the staged stream entry and the left boundary instead
             const int e = in_seg ? (int)ring[seg * PC_WIN + (t & (PC_WIN - 1))] : 0;
-            const bool rst = (e & PCF_RESET) != 0;
-            h_i = rst ? -1 : h_i + 1;                                  // row index of this entry
-            const int hb = rst ? -PC_OPEN : -(2 * PC_OPEN) - h_i * PC_EXT;   // H(i,-1) - 11; virtual row: H(-1,-1) - 11
+            const int hb = (e & PCF_RESET) ? -12 : -22;               // Ho^(-1,-1) on the virtual row, else Ho^(i,-1)
             a = is_head ? e : a; Hol = is_head ? hb : Hol; El = is_head ? PC_NEG : El;
             SHl = is_head ? 0u : SHl; SEl = is_head ? 0u : SEl;
         }

@@ -105,6 +105,32 @@ def test_every_systolic_variant(gpu_ctx, native_built, w):
     assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
 
 
+@pytest.mark.parametrize("w", [4, 13])
+def test_big_buckets_all_segment_counts(gpu_ctx, native_built, w):
+    """Column genes whose lanes-per-segment run over 1..64 (so 1..16 segments per wave), each with
+    300 row sequences: tasks of 208 + 92 rows spread over 4 waves x nseg segments."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(7 + w)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    gs = (1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 16, 21, 22, 32, 33, 64)
+    g = Genome("cols")
+    for i, lanes in enumerate(gs):
+        g.add(f"c{i:02d}", "".join(aa[rng.integers(0, 20, w * lanes - (i % 2))]))
+    h = Genome("rows")
+    for i in range(300):
+        h.add(f"r{i:03d}", "".join(aa[rng.integers(0, 20, int(rng.integers(1, 60)))]))
+    pk = pack_genomes([g, h])
+    ncol = len(gs)
+    a = np.repeat(np.arange(ncol, ncol + 300, dtype=np.int32), ncol)
+    b = np.tile(np.arange(ncol, dtype=np.int32), 300)
+    gpu_ctx.upload(pk)
+    ident, diag = gpu_ctx.align_pairs(a, b, variant=w)
+    _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+    assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
+
+
 def test_round6_matches_python(gpu_ctx):
     rng = np.random.default_rng(9)
     xs = np.concatenate([

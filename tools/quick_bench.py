@@ -16,7 +16,7 @@ ap.add_argument("-n", type=int, default=2000)
 ap.add_argument("-p", type=int, default=5000)
 ap.add_argument("-m", default="peq")
 ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--check", type=int, default=0, help="check this many leading rows against the oracle")
+ap.add_argument("--check", type=int, default=0, help="check this many random pairs against the oracle")
 a = ap.parse_args()
 build.build_all()
 t0 = time.time(); pk = synth_packed(a.n, a.p); t1 = time.time()
@@ -33,7 +33,12 @@ for i in range(a.steps):
           f"tasks {st['n_tasks']} launches {st['n_align_launches']} GCUPS {gc:.1f}", flush=True)
 if a.check:
     from oracle import oracle as O
-    want, _, _ = O.fill_rows(pk, a.m, 0, a.check, True)
+    rng = np.random.default_rng(1)
     n = a.n
-    k = sum(n - 1 - s for s in range(a.check))
-    print("oracle check rows", a.check, "pairs", k, "equal:", bool(np.array_equal(out[:k], want[:k])), flush=True)
+    s_idx = rng.integers(0, n - 1, a.check); t_idx = rng.integers(0, n, a.check)
+    lo, hi = np.minimum(s_idx, t_idx), np.maximum(s_idx, t_idx)
+    keep = lo < hi; lo, hi = lo[keep], hi[keep]
+    cond = lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)
+    want = O.pairs(pk, a.m, lo, hi, True)
+    print("oracle check: random pairs", lo.size, "equal:", bool(np.array_equal(out[cond], want)),
+          "mismatches", int((out[cond] != want).sum()), flush=True)

@@ -16,8 +16,8 @@ from phamclust_amd.pack import pack_genomes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--lens", default="60,100,150,207,260,330,420,520,640,800,1000,1200")
-ap.add_argument("--rows", type=int, default=256)
-ap.add_argument("--cols", type=int, default=96)
+ap.add_argument("--rows", type=int, default=208)
+ap.add_argument("--cols", type=int, default=1536)
 ap.add_argument("--variants", default="4,6,8,10,12,13,14,16,18,20")
 a = ap.parse_args()
 build.build_all()
