@@ -77,6 +77,8 @@ struct pc_ctx {
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // alignment launches of different classes overlap on these
+    hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static int set_device(pc_ctx* c) { PC_HIP(hipSetDevice(c->device)); return PC_OK; }
@@ -93,6 +95,8 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_plan, 4096, hipHostMallocDefault);
     if (e != hipSuccess) { pc_set_error("pc_ctx_create: %s", hipGetErrorString(e)); pc_ctx_destroy(c); return PC_ERR_HIP; }
     *out = c;
@@ -110,6 +114,8 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
                       &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 3; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
+    for (int i = 0; i < 4; ++i) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
     if (c->h_plan) (void)hipHostFree(c->h_plan);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -288,21 +294,39 @@ extern "C" int64_t pc_shard_pairs(const pc_ctx* c) { return c && c->uploaded ? c
 extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? c->shard_stride : -1; }
 
 // Steps 5 of the plan: launch the alignment kernels for every class that has tasks.
+// Step 5 of the plan: launch the alignment kernels for every class that has tasks.  Classes are
+// independent (disjoint result slots), so their launches are spread over the caller's stream and
+// three auxiliary streams: the drain of one class overlaps the next one's start.
 static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats) {
     const int ncls = (int)c->cls_variant.size();
-    for (int i = 0; i < ncls; ++i) {
+    std::vector<int> order;
+    for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](int x, int y) {
+        const uint32_t nx = task_begin[x + 1] - task_begin[x], ny = task_begin[y + 1] - task_begin[y];
+        return nx != ny ? nx > ny : x < y;
+    });
+    if (order.empty()) return PC_OK;
+    PC_HIP(hipEventRecord(c->aux_ev[3], st));
+    for (int k = 0; k < 3; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[3], 0));
+    int slot = 0;
+    for (int i : order) {
         const int nt = (int)(task_begin[i + 1] - task_begin[i]);
-        if (nt <= 0) continue;
         void* scratch = nullptr; size_t sbytes = 0;
+        hipStream_t ls = slot == 0 ? st : c->aux[slot - 1];
         if (c->cls_variant[i] < 0) {
             sbytes = pc_nw_fallback_scratch_bytes(c->cls_max_lb[i]);
             int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc;
             scratch = c->b_scratch.p;
         }
         int rc = pc_launch_nw(c->cls_variant[i], c->dev, c->b_tasks.as<PcTask>() + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
-                              c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, c->cls_max_lb[i], st);
+                              c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, c->cls_max_lb[i], ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
+        slot = (slot + 1) & 3;
+    }
+    for (int k = 0; k < 3; ++k) {
+        PC_HIP(hipEventRecord(c->aux_ev[k], c->aux[k]));
+        PC_HIP(hipStreamWaitEvent(st, c->aux_ev[k], 0));
     }
     return PC_OK;
 }

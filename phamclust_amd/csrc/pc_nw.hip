@@ -380,14 +380,16 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
 }
 
 // columns-per-lane of the compiled systolic variants
-static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20};
+static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24};
 static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 
 int pc_nw_num_variants() { return g_num_variants; }
 int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
 
-// Variant for a column gene of lb residues: minimise modelled instruction slots per
-// alignment row, (19 W + 45) / nseg, over the variants whose 64*W columns cover lb.
+// Variant for a column gene of lb residues.  Measured on MI355X (profiles/r01_e_variant_gcups.txt): time per
+// row step ~ W + 4.4 + 0.47 nseg cell-equivalents (15-instruction cells + per-step overhead that grows with the
+// number of segments: resets, stream refills), during which a wave retires nseg rows of lb cells -> minimise
+// (W + 4.4 + 0.47 nseg) / nseg over the variants whose 64*W columns cover lb.
 int pc_nw_choose_variant(int lb) {
     if (lb <= 0) return -1;
     int best = -1; double best_cost = 0;
@@ -395,8 +397,8 @@ int pc_nw_choose_variant(int lb) {
         const int W = g_variant_w[v];
         const int G = (lb + W - 1) / W;
         if (G > 64) continue;
-        const int nseg = 64 / G;
-        const double cost = (19.0 * W + 45.0) / nseg;
+        int nseg = 64 / G; if (nseg > 16) nseg = 16;
+        const double cost = (W + 4.4 + 0.47 * nseg) / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
     return best;
@@ -433,7 +435,7 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
         switch (g_variant_w[variant]) {
 #define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
         PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
-        PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(16) PC_CASE(18) PC_CASE(20)
+        PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24)
 #undef PC_CASE
         default: pc_set_error("pc_launch_nw: no kernel for variant %d", variant); return PC_ERR_ARG;
         }

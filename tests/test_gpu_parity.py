@@ -74,7 +74,7 @@ def test_align_pairs_integer_outputs(gpu_ctx, native_built, variant):
     assert np.array_equal(diag, want_d)
 
 
-@pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20])
+@pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24])
 def test_every_systolic_variant(gpu_ctx, native_built, w):
     """Each compiled columns-per-lane variant, forced, on column genes from 1 residue up to its
     64*w limit, many rows per column gene (streams of back-to-back alignments, several segments)."""
@@ -196,7 +196,7 @@ def test_long_and_ragged_sequences(gpu_ctx, native_built):
     O = _oracle()
     rng = np.random.default_rng(21)
     aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
-    lens = [1, 2, 3, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 513, 1279, 1280, 1281, 1500, 2100]
+    lens = [1, 2, 3, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 513, 1279, 1280, 1281, 1535, 1536, 1537, 2100]
     gs = []
     for gi in range(3):
         g = Genome(f"g{gi}")

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lens", default="60,100,150,207,260,330,420,520,640,800,1000,1200")
 ap.add_argument("--rows", type=int, default=208)
 ap.add_argument("--cols", type=int, default=1536)
-ap.add_argument("--variants", default="4,6,8,10,12,13,14,16,18,20")
+ap.add_argument("--variants", default="8,10,12,13,14,15,16,17,18,19,20,22,24")
 a = ap.parse_args()
 build.build_all()
 rng = np.random.default_rng(1)
