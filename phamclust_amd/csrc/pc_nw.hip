@@ -167,11 +167,11 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
 // One cell.  In: D, SD (this cell's diagonal candidates), chain (Hol, El, SHl, SEl), row code ac.
 // In/out (in place): column state Hou -> Ho, Fu -> F, SHu -> SH, SFu -> SF.
 // Out: E, SE (chain), and for the next cell Dn = old Hou + sp_next, SDn = old SHu + 0x10000 + (ac == bcn).
-#define PC_CELL_BODY(SDWA_NEXT, NEXT_LINES)                                                     \
+#define PC_CELL_BODY(CMP_LINE, NEXT_LINES)                                                     \
     asm volatile(                                                                               \
         "v_cmp_gt_i32 %[c0], %[Hol], %[El]\n\t"                                                 \
         "v_cmp_gt_i32 %[c1], %[Hou], %[Fu]\n\t"                                                 \
-        "v_cmp_eq_u32 %[c2], %[ac], %[bcn]\n\t"                                                 \
+        CMP_LINE                                                                                \
         "v_max_i32 %[E], %[Hol], %[El]\n\t"                                                     \
         "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
         "v_max_i32 %[Fu], %[Hou], %[Fu]\n\t"                                                    \
@@ -189,6 +189,7 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
         : [D] "v"(D), [SD] "v"(SD), [Hol] "v"(Hol), [El] "v"(El), [SHl] "v"(SHl), [SEl] "v"(SEl), [ac] "v"(ac),  \
           [bcn] "v"(bcn), [pwn] "v"(pwn), [K] "v"(K))
 
+#define PC_CMP(SEL) "v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:DWORD src1_sel:" SEL "\n\t"
 #define PC_NEXT(SEL)                                                                             \
     "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
     "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
@@ -199,22 +200,22 @@ __device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El,
                                             int& Dn, uint32_t& SDn, int ac, int bcn, uint32_t pwn, uint32_t K) {
     int H; uint32_t T;
     unsigned long long c0, c1, c2, c3, c4;
-    if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(0, PC_NEXT("BYTE_0"));
-    else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(1, PC_NEXT("BYTE_1"));
-    else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(2, PC_NEXT("BYTE_2"));
-    else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(3, PC_NEXT("BYTE_3"));
-    else { PC_CELL_BODY(-1, ""); Dn = 0; SDn = 0; }
+    if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(PC_CMP("BYTE_0"), PC_NEXT("BYTE_0"));
+    else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(PC_CMP("BYTE_1"), PC_NEXT("BYTE_1"));
+    else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(PC_CMP("BYTE_2"), PC_NEXT("BYTE_2"));
+    else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(PC_CMP("BYTE_3"), PC_NEXT("BYTE_3"));
+    else { PC_CELL_BODY("", ""); Dn = 0; SDn = 0; }
 }
 
 template <int W, int C>
 struct PcRow {          // compile-time unrolled sweep over the lane's W columns
     static __device__ __forceinline__ void run(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl, int (&Hou)[W],
-                                               int (&Fu)[W], uint32_t (&SHu)[W], uint32_t (&SFu)[W], const int (&bc)[W],
+                                               int (&Fu)[W], uint32_t (&SHu)[W], uint32_t (&SFu)[W], const uint32_t (&bc)[(W + 3) / 4],
                                                const uint32_t (&pw)[(W + 3) / 4], int ac, uint32_t K, int& E_out, uint32_t& SE_out) {
         int E, Dn; uint32_t SE, SDn;
         constexpr int NB = (C + 1 < W) ? ((C + 1) & 3) : -1;
         pc_cell_asm<NB>(D, SD, Hol, El, SHl, SEl, Hou[C], Fu[C], SHu[C], SFu[C], E, SE, Dn, SDn, ac,
-                        bc[(C + 1 < W) ? C + 1 : C], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
+                        (int)bc[(C + 1 < W) ? ((C + 1) >> 2) : 0], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
         if constexpr (C + 1 < W)
             PcRow<W, C + 1>::run(Dn, SDn, Hou[C], E, SHu[C], SE, Hou, Fu, SHu, SFu, bc, pw, ac, K, E_out, SE_out);
         else { E_out = E; SE_out = SE; }
@@ -265,9 +266,18 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     // wave-local row lr <-> task row (lr / nseg) * NS + wv * nseg + lr % nseg  (monotone in lr)
     auto task_row = [&](int lr) { return (lr / nseg) * NS + wv * nseg + (lr % nseg); };
 
-    int bc[W];
+    uint32_t bc[ND];                                 // my W column codes, 4 per register (compared with SDWA byte selects)
 #pragma unroll
-    for (int c = 0; c < W; ++c) { const int j = k * W + c; bc[c] = (in_seg && j < lb) ? (int)bp[j] : PC_PADCODE; }
+    for (int q = 0; q < ND; ++q) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = k * W + q * 4 + e;
+            const uint32_t code = (q * 4 + e < W && in_seg && j < lb) ? (uint32_t)bp[j] : (uint32_t)PC_PADCODE;
+            v |= code << (8 * e);
+        }
+        bc[q] = v;
+    }
     __syncthreads();                                 // score table visible
     if (seg == 0) {                                  // each wave's segment-0 lanes write 6 of the 24 profile rows
 #pragma unroll 1
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = q * 4 + e;
-                    if (c < W) v |= (uint32_t)(uint8_t)tab[r][min(bc[c], 23)] << (8 * e);
+                    if (c < W) v |= (uint32_t)(uint8_t)tab[r][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
                 }
                 prof[(r * G + k) * ND + q] = v;
             }
@@ -308,67 +318,84 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     int Hou[W], Fu[W]; uint32_t SHu[W], SFu[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; SHu[c] = 0; SFu[c] = 0; }
-    int o_a = 0, o_E = PC_NEG; uint32_t o_SE = 0;   // my last column's E/SE and the row code, previous step
+    int o_E = PC_NEG; uint32_t o_SE = 0;            // my last column's E / SE of the previous step
     int p_Hol = PC_NEG; uint32_t p_SHl = 0;         // what I received last step (diagonal of column 0)
     int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
     const int half = lane >> 5, hl = lane & 31;
+    const uint32_t prof_lane = (uint32_t)(k * ND) * 4u;            // byte offset of my strip inside a profile row
+    const uint32_t prof_rowb = (uint32_t)(G * ND) * 4u;            // bytes per profile row
+    const uint32_t ring_lane = (uint32_t)(in_seg ? seg : 0) * PC_WIN;
+
+    // Stage PC_WIN stream entries of every segment starting at stream position `base` (two segments per pass).
+    auto refill = [&](int base) {
+        pc_wave_lds_sync();
+        for (int s0 = 0; s0 < nseg; s0 += 2) {
+            const int sg = s0 + half;
+            uint32_t entry = 0;
+            if (sg < nseg) {
+                const uint32_t p = (uint32_t)base + hl;
+                if (p < seg_len[sg]) {
+                    int r = (int)seg_cur[sg];
+                    while (p >= row_pos[r] + row_la[r] + 1) r += nseg;
+                    const int i = (int)(p - row_pos[r]) - 1;
+                    if (i < 0) entry = PCF_RESET;
+                    else {
+                        const uint8_t* ap = d.codes + (((unsigned long long)row_hi[r] << 32) | row_lo[r]);
+                        entry = (uint32_t)ap[i] | (i == (int)row_la[r] - 1 ? PCF_LAST : 0);
+                    }
+                    if (hl == PC_WIN - 1) seg_cur[sg] = (uint32_t)r;
+                }
+                ring[sg * PC_WIN + hl] = (uint16_t)entry;
+            }
+        }
+        pc_wave_lds_sync();
+    };
+    auto load_prof = [&](int code, uint32_t (&dst)[ND]) {           // my strip of profile row min(code, 23)
+        const uint32_t off = (uint32_t)__mul24(min(code & 0xff, 23), (int)prof_rowb) + prof_lane;
+        const uint32_t* pr = (const uint32_t*)((const char*)prof + off);
+#pragma unroll
+        for (int q = 0; q < ND; ++q) dst[q] = pr[q];
+    };
+
+    // Software pipeline: at step t the row code `a` and its profile strip `pw` are already in registers; the
+    // code of step t+1 (head: ring entry, others: the left neighbour's current code) and its strip are fetched
+    // while the cells of step t execute, and the head's ring entry of step t+2 is read one step ahead of that.
+    refill(0);
+    int a = is_head ? (int)ring[ring_lane] : 0;
+    int e_nxt = in_seg ? (int)ring[ring_lane + 1] : 0;             // head's entry for step 1 (PC_WIN >= 2)
+    uint32_t pw[ND];
+    load_prof(a, pw);
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        if ((t & (PC_WIN - 1)) == 0) {
-            // ---- stage the next PC_WIN stream entries of every segment (two segments per pass) ----
-            pc_wave_lds_sync();
-            for (int s0 = 0; s0 < nseg; s0 += 2) {
-                const int sg = s0 + half;
-                uint32_t entry = 0;
-                if (sg < nseg) {
-                    const uint32_t p = (uint32_t)t + hl;
-                    if (p < seg_len[sg]) {
-                        int r = (int)seg_cur[sg];
-                        while (p >= row_pos[r] + row_la[r] + 1) r += nseg;
-                        const int i = (int)(p - row_pos[r]) - 1;
-                        if (i < 0) entry = PCF_RESET;
-                        else {
-                            const uint8_t* ap = d.codes + (((unsigned long long)row_hi[r] << 32) | row_lo[r]);
-                            entry = (uint32_t)ap[i] | (i == (int)row_la[r] - 1 ? PCF_LAST : 0);
-                        }
-                        if (hl == PC_WIN - 1) seg_cur[sg] = (uint32_t)r;
-                    }
-                    ring[sg * PC_WIN + hl] = (uint16_t)entry;
-                }
-            }
-            pc_wave_lds_sync();
-        }
+        if (((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         asm volatile("s_nop 1" ::: "memory");        // VALU (asm, previous step) -> DPP read: 2 wait states
-        int a = pc_shr1(o_a);
-        int Hol = pc_shr1(Hou[W - 1]);
-        int El = pc_shr1(o_E);
-        uint32_t SHl = (uint32_t)pc_shr1((int)SHu[W - 1]);
-        uint32_t SEl = (uint32_t)pc_shr1((int)o_SE);
-        {   // head lanes take the staged stream entry and the left boundary instead
-            const int e = in_seg ? (int)ring[seg * PC_WIN + (t & (PC_WIN - 1))] : 0;
-            const int hb = (e & PCF_RESET) ? -12 : -22;               // Ho^(-1,-1) on the virtual row, else Ho^(i,-1)
-            a = is_head ? e : a; Hol = is_head ? hb : Hol; El = is_head ? PC_NEG : El;
+        const int a_nxt = is_head ? e_nxt : __builtin_amdgcn_mov_dpp(a, 0x138, 0xf, 0xf, true);
+        uint32_t pw_nxt[ND];
+        load_prof(a_nxt, pw_nxt);
+        e_nxt = in_seg ? (int)ring[ring_lane + ((t + 2) & (PC_WIN - 1))] : 0;
+        int Hol = __builtin_amdgcn_mov_dpp(Hou[W - 1], 0x138, 0xf, 0xf, true);
+        int El = __builtin_amdgcn_mov_dpp(o_E, 0x138, 0xf, 0xf, true);
+        uint32_t SHl = (uint32_t)__builtin_amdgcn_mov_dpp((int)SHu[W - 1], 0x138, 0xf, 0xf, true);
+        uint32_t SEl = (uint32_t)__builtin_amdgcn_mov_dpp((int)o_SE, 0x138, 0xf, 0xf, true);
+        const bool rst = (a & PCF_RESET) != 0;
+        {   // head lanes: left boundary Ho^(i,-1) = -22, or Ho^(-1,-1) = -12 on the virtual row
+            const int hb = rst ? -12 : -22;
+            Hol = is_head ? hb : Hol; El = is_head ? PC_NEG : El;
             SHl = is_head ? 0u : SHl; SEl = is_head ? 0u : SEl;
         }
         int Hod = p_Hol; uint32_t SHd = p_SHl;
         p_Hol = Hol; p_SHl = SHl;
-        if (__builtin_amdgcn_ballot_w64((a & PCF_RESET) != 0) != 0) {     // some lane starts an alignment this step
-            const bool rst = (a & PCF_RESET) != 0;
+        if (__builtin_amdgcn_ballot_w64(rst) != 0) {                     // some lane starts an alignment this step
 #pragma unroll
             for (int c = 0; c < W; ++c) { Hou[c] = rst ? PC_NEG : Hou[c]; Fu[c] = rst ? PC_NEG : Fu[c]; }
             Hod = rst ? PC_NEG : Hod;
         }
         const int ac = a & 0xff;
-        const uint32_t* pr = prof + (min(ac, 23) * G + k) * ND;
-        uint32_t pw[ND];
-#pragma unroll
-        for (int q = 0; q < ND; ++q) pw[q] = pr[q];
         const int D0 = Hod + (int)(pw[0] & 0xffu);
-        const uint32_t SD0 = SHd + K + (ac == bc[0] ? 1u : 0u);
+        const uint32_t SD0 = SHd + K + (ac == (int)(bc[0] & 0xffu) ? 1u : 0u);
         PcRow<W, 0>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, ac, K, o_E, o_SE);
-        o_a = a;
         if ((a & PCF_LAST) && is_out) {
             uint32_t st = SHu[0];
 #pragma unroll
@@ -376,6 +403,9 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
             res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
             out_r += nseg;
         }
+        a = a_nxt;
+#pragma unroll
+        for (int q = 0; q < ND; ++q) pw[q] = pw_nxt[q];
     }
 }
 

@@ -87,58 +87,81 @@ __device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh,
 
 // ---------------------------------------------------------------------------------
 // K1+K3: gcs / jc.  shared = popcount(B[s] & B[t]); fp64 epilogue.  One workgroup per
-// 32x32 tile, 4 pairs per thread.  The fast thread index runs along the output's
-// contiguous direction (t for condensed order, s for shard-local order).
+// 64x64 tile of pairs, a 4x4 register tile of pairs per thread: per bitmap word a thread
+// reads 4 source-row words and 4 target-row words from LDS (broadcast / conflict-free with
+// the odd row stride) and does 16 AND+popcount pairs, so LDS traffic per popcount is 4x
+// lower than one-pair-per-load and the kernel is VALU (popcount) bound, then output bound.
+// Lanes 0..15 of a 16-lane group hold consecutive t, so each store instruction writes
+// 128-byte runs of the condensed (row-major upper-triangle) output.
 // ---------------------------------------------------------------------------------
+#define PT 64          // popcount tile edge
+#define PWCH 32        // bitmap words staged per chunk
+
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed) {
-    __shared__ uint64_t rs[TS][WCH + 1];
-    __shared__ uint64_t rt[TS][WCH + 1];
-    const int s0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
-    const int klast = min(k0 + TS, sh.nown) - 1;
+    __shared__ uint64_t rs[PT][PWCH + 1];
+    __shared__ uint64_t rt[PT][PWCH + 1];
+    const int s0 = blockIdx.x * PT, k0 = blockIdx.y * PT;
+    const int klast = min(k0 + PT, sh.nown) - 1;
     if (s0 >= sh.owned[klast]) return;                       // tile entirely on/below the diagonal
-    const int f = threadIdx.x & 31, q = threadIdx.x >> 5;
-    int acc[4] = {0, 0, 0, 0};
-    for (int w0 = 0; w0 < d.Wb; w0 += WCH) {
-        const int wn = min(WCH, d.Wb - w0);
+    // fast index along the output's contiguous direction: t (condensed) or s (shard-local)
+    const int fx = threadIdx.x & 15, fy = threadIdx.x >> 4;
+    const int ls0 = condensed ? fy : fx, lt0 = condensed ? fx : fy;    // + 16*i
+    int acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
+        const int wn = min(PWCH, d.Wb - w0);
         if (w0) __syncthreads();
-        pc_stage_tile(d, sh, s0, k0, w0, wn, rs, rt);
+        for (int r = threadIdx.x >> 5; r < PT; r += 8) {       // stage 64 + 64 rows, 32 words (256 B) per row per pass
+            const int s = s0 + r, k = k0 + r;
+            const int w = threadIdx.x & 31;
+            uint64_t vs = 0, vt = 0;
+            if (w < wn) {
+                if (s < d.N) vs = d.bitmap[(int64_t)s * d.Wstride + w0 + w];
+                if (k < sh.nown) vt = d.bitmap[(int64_t)sh.owned[k] * d.Wstride + w0 + w];
+            }
+            rs[r][w] = vs; rt[r][w] = vt;
+        }
         __syncthreads();
-        if (condensed) {
-            for (int w = 0; w < wn; ++w) {
-                uint64_t tw = rt[f][w];
+        for (int w = 0; w < wn; ++w) {
+            uint64_t a[4], b[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] += __popcll(rs[q + 8 * m][w] & tw);
-            }
-        } else {
-            for (int w = 0; w < wn; ++w) {
-                uint64_t sw = rs[f][w];
+            for (int i = 0; i < 4; ++i) { a[i] = rs[ls0 + 16 * i][w]; b[i] = rt[lt0 + 16 * i][w]; }
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] += __popcll(rt[q + 8 * m][w] & sw);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int ls = condensed ? q + 8 * m : f, lt = condensed ? f : q + 8 * m;
-        const int s = s0 + ls, k = k0 + lt;
-        if (s >= d.N || k >= sh.nown) continue;
-        const int t = sh.owned[k];
-        if (s >= t) continue;
-        const int shared = acc[m];
-        double sim = 0.0;
-        if (shared) {
-            const int tot = d.nph[s] + d.nph[t];
-            if (METRIC == PC_GCS) sim = (2.0 * (double)shared) / (double)tot;      // metrics.py:45-48
-            else sim = (double)shared / (double)(tot - shared);                     // metrics.py:75
+    for (int i = 0; i < 4; ++i) {
+        const int s = s0 + ls0 + 16 * i;
+        if (s >= d.N) continue;
+        const int nps = d.nph[s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + lt0 + 16 * j;
+            if (k >= sh.nown) continue;
+            const int t = sh.owned[k];
+            if (s >= t) continue;
+            const int shared = acc[i][j];
+            double sim = 0.0;
+            if (shared) {
+                const int tot = nps + d.nph[t];
+                if (METRIC == PC_GCS) sim = (2.0 * (double)shared) / (double)tot;      // metrics.py:45-48
+                else sim = (double)shared / (double)(tot - shared);                     // metrics.py:75
+            }
+            out[pc_out_index(d, sh, s, t, k, condensed)] = pc_finish(sim, as_distance);
         }
-        out[pc_out_index(d, sh, s, t, k, condensed)] = pc_finish(sim, as_distance);
     }
 }
 
 int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
-    dim3 grid((d.N + TS - 1) / TS, (sh.nown + TS - 1) / TS);
+    dim3 grid((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT);
     if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed);
     else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed);
     hipError_t e = hipGetLastError();
