@@ -371,7 +371,10 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     for (int t = 0; t < T; ++t) {
         if (((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         asm volatile("s_nop 1" ::: "memory");        // VALU (asm, previous step) -> DPP read: 2 wait states
-        const int a_nxt = is_head ? e_nxt : __builtin_amdgcn_mov_dpp(a, 0x138, 0xf, 0xf, true);
+        // the DPP shift must run with every lane active (a masked-off source lane reads as 0), so it is
+        // computed unconditionally and selected afterwards -- never inside the branch of a ?:
+        const int a_left = __builtin_amdgcn_mov_dpp(a, 0x138, 0xf, 0xf, true);
+        const int a_nxt = is_head ? e_nxt : a_left;
         uint32_t pw_nxt[ND];
         load_prof(a_nxt, pw_nxt);
         e_nxt = in_seg ? (int)ring[ring_lane + ((t + 2) & (PC_WIN - 1))] : 0;
