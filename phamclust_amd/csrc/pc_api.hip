@@ -59,7 +59,7 @@ struct pc_ctx {
     bool uploaded = false;
     PcDev dev{};
     std::vector<int32_t> h_gene_len;
-    int max_gene_len = 0, min_gene_len = 0;
+    int max_gene_len = 0, min_gene_len = 0, max_nph = 0;
     // kernel-variant classes over column genes
     std::vector<int> cls_variant;           // per class: variant id, -1 = general kernel
     std::vector<int32_t> cls_begin;         // [ncls+1] positions in class order
@@ -73,7 +73,7 @@ struct pc_ctx {
     DevBuf b_cls_order, b_cls_idx, b_owned, b_lbase;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_col_cnt, b_col_start, b_col_cur, b_cnt_q, b_start_q, b_ntask_q, b_task_off_q, b_scan_tmp;
-    DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out;
+    DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -111,7 +111,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
                       &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_cls_order, &c->b_cls_idx, &c->b_owned, &c->b_lbase,
                       &c->b_na, &c->b_off, &c->b_col_cnt, &c->b_col_start, &c->b_col_cur, &c->b_cnt_q, &c->b_start_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_bucket_row, &c->b_bucket_dest,
-                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out};
+                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 3; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -277,6 +277,8 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
+    c->max_nph = 0;
+    for (int s2 = 0; s2 < N; ++s2) c->max_nph = std::max(c->max_nph, (int)g->nph[s2]);
     rc = apply_shard(c, 0, 1);
     if (rc != PC_OK) return rc;
     c->uploaded = true;
@@ -345,7 +347,14 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     PC_HIP(hipEventRecord(c->ev[0], st));
 
     if (metric == PC_GCS || metric == PC_JC) {
-        rc = pc_launch_set_popc(d, c->shard, metric, as_distance, out, condensed, st);
+        // epilogue table over (shared, nph_s + nph_t): at most (max_nph+1) x (2 max_nph+1) doubles; skipped when huge
+        const int sh_dim = c->max_nph + 1, tot_dim = 2 * c->max_nph + 1;
+        double* lut = nullptr;
+        if ((int64_t)sh_dim * tot_dim <= (4 << 20)) {
+            if ((rc = c->b_lut.ensure((size_t)sh_dim * tot_dim * 8))) return rc;
+            lut = c->b_lut.as<double>();
+        }
+        rc = pc_launch_set_popc(d, c->shard, metric, as_distance, out, condensed, lut, sh_dim, tot_dim, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
     } else if (metric == PC_POCP || metric == PC_AF) {

@@ -86,36 +86,58 @@ __device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh,
 }
 
 // ---------------------------------------------------------------------------------
-// K1+K3: gcs / jc.  shared = popcount(B[s] & B[t]); fp64 epilogue.  One workgroup per
-// 64x64 tile of pairs, a 4x4 register tile of pairs per thread: per bitmap word a thread
-// reads 4 source-row words and 4 target-row words from LDS (broadcast / conflict-free with
-// the odd row stride) and does 16 AND+popcount pairs, so LDS traffic per popcount is 4x
-// lower than one-pair-per-load and the kernel is VALU (popcount) bound, then output bound.
-// Lanes 0..15 of a 16-lane group hold consecutive t, so each store instruction writes
-// 128-byte runs of the condensed (row-major upper-triangle) output.
+// K1+K3: gcs / jc.  shared = popcount(B[s] & B[t]); fp64 epilogue.  One 512-thread workgroup
+// per 64x64 tile of pairs, a 2x4 register tile of pairs per thread: per bitmap word a thread
+// reads 2 source-row words and 4 target-row words from LDS (broadcast / conflict-free with
+// the odd row stride) and does 8 AND+popcount pairs.  Lanes 0..15 of a 16-lane group hold
+// consecutive t, so each store instruction writes 128-byte runs of the condensed output.
+// The epilogue value depends only on the two small integers (shared, nph_s + nph_t), so it is
+// looked up in a table built once per fill by k_set_lut (exactly the same fp64 code path:
+// division, 1 - x, round(., 6)); without a table (huge genomes) it is computed in place.
 // ---------------------------------------------------------------------------------
 #define PT 64          // popcount tile edge
 #define PWCH 32        // bitmap words staged per chunk
 
 template <int METRIC>
-__global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed) {
+__device__ __forceinline__ double pc_set_value(int shared, int tot, int as_distance) {
+    double sim = 0.0;
+    if (shared) {
+        if (METRIC == PC_GCS) sim = (2.0 * (double)shared) / (double)tot;      // metrics.py:45-48
+        else sim = (double)shared / (double)(tot - shared);                     // metrics.py:75
+    }
+    return pc_finish(sim, as_distance);
+}
+
+template <int METRIC>
+__global__ void k_set_lut(double* __restrict__ lut, int sh_dim, int tot_dim, int as_distance) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh_dim * tot_dim) return;
+    const int tot = i / sh_dim, shared = i - tot * sh_dim;
+    // entries with shared > tot/2 (gcs) or shared > tot - shared (jc) never occur; keep them finite
+    const bool possible = 2 * shared <= tot;
+    lut[i] = possible ? pc_set_value<METRIC>(shared, tot, as_distance) : 0.0;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(512) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
+                                                   const double* __restrict__ lut, int sh_dim) {
     __shared__ uint64_t rs[PT][PWCH + 1];
     __shared__ uint64_t rt[PT][PWCH + 1];
     const int s0 = blockIdx.x * PT, k0 = blockIdx.y * PT;
     const int klast = min(k0 + PT, sh.nown) - 1;
     if (s0 >= sh.owned[klast]) return;                       // tile entirely on/below the diagonal
-    // fast index along the output's contiguous direction: t (condensed) or s (shard-local)
-    const int fx = threadIdx.x & 15, fy = threadIdx.x >> 4;
-    const int ls0 = condensed ? fy : fx, lt0 = condensed ? fx : fy;    // + 16*i
-    int acc[4][4];
+    // fast index (16 lanes) along the output's contiguous direction: t (condensed) or s (shard-local)
+    const int fx = threadIdx.x & 15, fy = threadIdx.x >> 4;  // fy: 0..31
+    // the fast direction holds 4 values per thread (+16j), the slow one 2 (+32i)
+    int acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0;
     for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
         const int wn = min(PWCH, d.Wb - w0);
         if (w0) __syncthreads();
-        for (int r = threadIdx.x >> 5; r < PT; r += 8) {       // stage 64 + 64 rows, 32 words (256 B) per row per pass
+        for (int r = threadIdx.x >> 5; r < PT; r += 16) {      // stage 64 + 64 rows, 32 words (256 B) per row per pass
             const int s = s0 + r, k = k0 + r;
             const int w = threadIdx.x & 31;
             uint64_t vs = 0, vt = 0;
@@ -126,44 +148,60 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
             rs[r][w] = vs; rt[r][w] = vt;
         }
         __syncthreads();
-        for (int w = 0; w < wn; ++w) {
-            uint64_t a[4], b[4];
+        if (condensed) {
+            for (int w = 0; w < wn; ++w) {
+                uint64_t a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = rs[ls0 + 16 * i][w]; b[i] = rt[lt0 + 16 * i][w]; }
+                for (int i = 0; i < 2; ++i) a[i] = rs[fy + 32 * i][w];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) b[j] = rt[fx + 16 * j][w];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
+            }
+        } else {
+            for (int w = 0; w < wn; ++w) {
+                uint64_t a[2], b[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = rt[fy + 32 * i][w];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = rs[fx + 16 * j][w];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = s0 + ls0 + 16 * i;
-        if (s >= d.N) continue;
-        const int nps = d.nph[s];
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = k0 + lt0 + 16 * j;
-            if (k >= sh.nown) continue;
+            const int ls = condensed ? fy + 32 * i : fx + 16 * j;
+            const int lt = condensed ? fx + 16 * j : fy + 32 * i;
+            const int s = s0 + ls, k = k0 + lt;
+            if (s >= d.N || k >= sh.nown) continue;
             const int t = sh.owned[k];
             if (s >= t) continue;
-            const int shared = acc[i][j];
-            double sim = 0.0;
-            if (shared) {
-                const int tot = nps + d.nph[t];
-                if (METRIC == PC_GCS) sim = (2.0 * (double)shared) / (double)tot;      // metrics.py:45-48
-                else sim = (double)shared / (double)(tot - shared);                     // metrics.py:75
-            }
-            out[pc_out_index(d, sh, s, t, k, condensed)] = pc_finish(sim, as_distance);
+            const int shared = acc[i][j], tot = d.nph[s] + d.nph[t];
+            const double v = lut ? lut[tot * sh_dim + shared] : pc_set_value<METRIC>(shared, tot, as_distance);
+            out[pc_out_index(d, sh, s, t, k, condensed)] = v;
         }
     }
 }
 
-int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed, hipStream_t st) {
+int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed,
+                       double* lut, int sh_dim, int tot_dim, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
     dim3 grid((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT);
-    if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed);
-    else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed);
+    if (lut) {
+        const int n = sh_dim * tot_dim;
+        if (metric == PC_GCS) hipLaunchKernelGGL(k_set_lut<PC_GCS>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
+        else hipLaunchKernelGGL(k_set_lut<PC_JC>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
+    }
+    if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(512), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+    else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(512), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_set_popc launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
