@@ -230,7 +230,8 @@ __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read
 }
 
 template <int W>
-__global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+__global__ __launch_bounds__(64 * PC_WAVES, (W <= 14 ? 5 : (W <= 20 ? 4 : 3)))   // waves/SIMD the register budget must allow
+void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
                                                                const uint32_t* __restrict__ bucket_dest,
                                                                uint2* __restrict__ res) {
