@@ -167,19 +167,20 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
 // One cell.  In: D, SD (this cell's diagonal candidates), chain (Hol, El, SHl, SEl), row code ac.
 // In/out (in place): column state Hou -> Ho, Fu -> F, SHu -> SH, SFu -> SF.
 // Out: E, SE (chain), and for the next cell Dn = old Hou + sp_next, SDn = old SHu + 0x10000 + (ac == bcn).
-#define PC_CELL_BODY(CMP_LINE, NEXT_LINES)                                                     \
+#define PC_CELL_BODY(CMP_LINE, NEXT_D, NEXT_SD)                                                 \
     asm volatile(                                                                               \
         "v_cmp_gt_i32 %[c0], %[Hol], %[El]\n\t"                                                 \
         "v_cmp_gt_i32 %[c1], %[Hou], %[Fu]\n\t"                                                 \
         CMP_LINE                                                                                \
         "v_max_i32 %[E], %[Hol], %[El]\n\t"                                                     \
-        "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
         "v_max_i32 %[Fu], %[Hou], %[Fu]\n\t"                                                    \
-        "v_cndmask_b32 %[SFu], %[SFu], %[SHu], %[c1]\n\t"                                       \
-        NEXT_LINES                                                                              \
+        NEXT_D                                                                                  \
         "v_max3_i32 %[H], %[D], %[E], %[Fu]\n\t"                                                \
         "v_cmp_eq_u32 %[c3], %[H], %[Fu]\n\t"                                                   \
         "v_cmp_eq_u32 %[c4], %[H], %[D]\n\t"                                                    \
+        "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
+        "v_cndmask_b32 %[SFu], %[SFu], %[SHu], %[c1]\n\t"                                       \
+        NEXT_SD                                                                                 \
         "v_add_u32 %[Hou], -10, %[H]\n\t"                                                       \
         "v_cndmask_b32 %[T], %[SE], %[SFu], %[c3]\n\t"                                          \
         "v_cndmask_b32 %[SHu], %[T], %[SD], %[c4]\n\t"                                          \
@@ -190,9 +191,8 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
           [bcn] "v"(bcn), [pwn] "v"(pwn), [K] "v"(K))
 
 #define PC_CMP(SEL) "v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:DWORD src1_sel:" SEL "\n\t"
-#define PC_NEXT(SEL)                                                                             \
-    "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
-    "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
+#define PC_NEXT_D(SEL) "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t"
+#define PC_NEXT_SD "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
 
 template <int NEXT_BYTE>   // byte of pwn holding the next cell's score; -1: last cell of the lane
 __device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl,
@@ -200,11 +200,11 @@ __device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El,
                                             int& Dn, uint32_t& SDn, int ac, int bcn, uint32_t pwn, uint32_t K) {
     int H; uint32_t T;
     unsigned long long c0, c1, c2, c3, c4;
-    if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(PC_CMP("BYTE_0"), PC_NEXT("BYTE_0"));
-    else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(PC_CMP("BYTE_1"), PC_NEXT("BYTE_1"));
-    else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(PC_CMP("BYTE_2"), PC_NEXT("BYTE_2"));
-    else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(PC_CMP("BYTE_3"), PC_NEXT("BYTE_3"));
-    else { PC_CELL_BODY("", ""); Dn = 0; SDn = 0; }
+    if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(PC_CMP("BYTE_0"), PC_NEXT_D("BYTE_0"), PC_NEXT_SD);
+    else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(PC_CMP("BYTE_1"), PC_NEXT_D("BYTE_1"), PC_NEXT_SD);
+    else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(PC_CMP("BYTE_2"), PC_NEXT_D("BYTE_2"), PC_NEXT_SD);
+    else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(PC_CMP("BYTE_3"), PC_NEXT_D("BYTE_3"), PC_NEXT_SD);
+    else { PC_CELL_BODY("", "", ""); Dn = 0; SDn = 0; }
 }
 
 template <int W, int C>
@@ -230,8 +230,7 @@ __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read
 }
 
 template <int W>
-__global__ __launch_bounds__(64 * PC_WAVES, (W <= 14 ? 5 : (W <= 20 ? 4 : 3)))   // waves/SIMD the register budget must allow
-void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+__global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
                                                                const uint32_t* __restrict__ bucket_dest,
                                                                uint2* __restrict__ res) {

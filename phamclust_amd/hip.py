@@ -134,6 +134,7 @@ class Context:
                      _ptr(packed.seq_off, _i64p), _ptr(packed.residues, _u8p))
         self._check(self._lib.pc_upload(self._h, ctypes.byref(s)))
         self._packed = packed
+        self._shard = (0, 1)                      # pc_upload resets the shard to "everything"
         return self
 
     @property
@@ -145,7 +146,9 @@ class Context:
         return self._packed.n_pairs
 
     def set_shard(self, rank, world):
-        self._check(self._lib.pc_set_shard(self._h, int(rank), int(world)))
+        if getattr(self, "_shard", None) != (int(rank), int(world)):
+            self._check(self._lib.pc_set_shard(self._h, int(rank), int(world)))
+            self._shard = (int(rank), int(world))
 
     def shard_pairs(self):
         return int(self._lib.pc_shard_pairs(self._h))
