@@ -170,8 +170,23 @@ def main():
             "note": "integer-VALU bound recurrence (no MFMA, little HBM traffic): GCUPS is the meaningful rate; "
                     "HBM fraction reported because the north star asks for it",
         }
+        # the bound that actually binds: 32-bit integer VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
+        # (one wave64 VALU instruction occupies its SIMD for 4 clocks; SQ_ACTIVE_INST_VALU confirms it), and
+        # the hand-scheduled DP cell is 15 VALU instructions.
+        lane_ops_peak = 256 * 4 * 16 * 2.4e9
+        gc = line["roofline"]["gcups_per_gpu"]
+        line["roofline"]["valu"] = {"bound": "int32 VALU issue", "instr_per_cell": 15, "peak_gcups": lane_ops_peak / 15 / 1e9,
+                                    "achieved_gcups": gc, "frac": gc / (lane_ops_peak / 15 / 1e9)}
         if align_span:
             line["roofline"]["ms_kernels_min_max_over_ranks"] = align_span
+        try:                                              # PMC traffic measured offline for this exact workload, if any
+            with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
+                for e in json.load(fh)["entries"]:
+                    if e["workload"] == f"synth({a.genomes},{a.phams}) -m {a.metric}" and e["n_gpus"] == world:
+                        line["roofline"]["traffic"] = e["traffic_bytes_per_fill"]
+                        line["roofline"]["traffic_source"] = e["source"]
+        except (OSError, KeyError, ValueError):
+            pass
     else:
         nb = packed.n_genomes * packed.words_per_row * 8 + 16 * packed.n_genomes + 8 * n_pairs
         t = ms_dev / 1e3
@@ -179,6 +194,8 @@ def main():
                             "frac": nb / t / 1e9 / 8000.0 if t > 0 else 0.0, "traffic": None,
                             "kernel": "k_set_popc / k_walk", "algorithmic_bytes_per_fill": nb, "ms_kernels_per_fill": ms_dev}
     line["device_ms_per_fill"] = ms_dev
+    if world == 1:
+        line["stage_ms"] = {k: sum(s[k] for s in stats) / len(stats) for k in ("ms_plan", "ms_align", "ms_reduce")}
 
     if a.verify_pairs > 0 and n_pairs > 0:
         # sampled check of the assembled matrix against the oracle (random pairs over the whole triangle)

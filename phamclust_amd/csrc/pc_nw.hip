@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
         {   // head lanes: left boundary Ho^(i,-1) = -22, or Ho^(-1,-1) = -12 on the virtual row
             const int hb = rst ? -12 : -22;
             Hol = is_head ? hb : Hol; El = is_head ? PC_NEG : El;
-            SHl = is_head ? 0u : SHl; SEl = is_head ? 0u : SEl;
+            SHl = is_head ? 0u : SHl;                 // SEl needs no fix-up: with El = -inf the head's E always opens
         }
         int Hod = p_Hol; uint32_t SHd = p_SHl;
         p_Hol = Hol; p_SHl = SHl;
