@@ -2,6 +2,7 @@
 
 * ``csrc/libphamclust_hip.so``  hipcc, gfx950 only (cross-compiles without a GPU)
 * ``csrc/libpc_synth.so``       gcc, the synthetic-data generator
+* ``csrc/libpc_pack.so``        gcc, the TSV loader/packer
 The built files stay next to their sources so that they travel with the tree.
 """
 
@@ -13,6 +14,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 HIP_SOURCES = ["pc_api.hip", "pc_pairs.hip", "pc_nw.hip"]
 HIP_LIB = os.path.join(CSRC, "libphamclust_hip.so")
 SYNTH_LIB = os.path.join(CSRC, "libpc_synth.so")
+PACK_LIB = os.path.join(CSRC, "libpc_pack.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -55,8 +57,18 @@ def build_synth(force=False, verbose=False):
     return SYNTH_LIB
 
 
+def build_pack(force=False, verbose=False):
+    src = os.path.join(CSRC, "pc_pack.c")
+    if force or _stale(PACK_LIB, [src]):
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-o", PACK_LIB, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return PACK_LIB
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force, verbose)
+    return build_hip(force, verbose), build_synth(force, verbose), build_pack(force, verbose)
 
 
 if __name__ == "__main__":

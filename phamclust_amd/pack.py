@@ -133,3 +133,59 @@ def unpack_genomes(packed):
             genome.add(packed.pham_names[int(packed.gene_pham[k])], seq)
         genomes.append(genome)
     return genomes
+
+
+# ---------------------------------------------------------------------------------------
+# TSV -> PackedGenomes in C (csrc/pc_pack.c): no Python object per gene
+# ---------------------------------------------------------------------------------------
+def load_tsv_packed(filepath):
+    """Parse the reference's 2/3-column TSV (scripts/phamclust.py:21-47) straight into packed form,
+    genomes sorted by name (scripts/phamclust.py:221).  Equals pack_genomes(sorted(load_genomes_from_tsv))."""
+    import ctypes
+    import os
+
+    lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpc_pack.so")
+    if not os.path.exists(lib_path):
+        raise RuntimeError(f"{lib_path} is missing - run `python -m phamclust_amd.build` first")
+
+    class _Data(ctypes.Structure):
+        _fields_ = [("n_genomes", ctypes.c_int32), ("n_phams", ctypes.c_int32), ("words_per_row", ctypes.c_int32),
+                    ("status", ctypes.c_int32), ("n_genes", ctypes.c_int64), ("n_residues", ctypes.c_int64),
+                    ("names_bytes", ctypes.c_int64), ("pham_names_bytes", ctypes.c_int64),
+                    ("bitmap", ctypes.POINTER(ctypes.c_uint64)), ("nph", ctypes.POINTER(ctypes.c_int32)),
+                    ("ngen", ctypes.POINTER(ctypes.c_int32)), ("tlen", ctypes.POINTER(ctypes.c_int64)),
+                    ("gene_off", ctypes.POINTER(ctypes.c_int64)), ("gene_pham", ctypes.POINTER(ctypes.c_int32)),
+                    ("seq_off", ctypes.POINTER(ctypes.c_int64)), ("residues", ctypes.POINTER(ctypes.c_uint8)),
+                    ("names", ctypes.POINTER(ctypes.c_char)), ("name_off", ctypes.POINTER(ctypes.c_int64)),
+                    ("pham_names", ctypes.POINTER(ctypes.c_char)), ("pham_name_off", ctypes.POINTER(ctypes.c_int64)),
+                    ("file", ctypes.c_void_p), ("error", ctypes.c_char * 256)]
+
+    lib = ctypes.CDLL(lib_path)
+    lib.pcp_load_tsv.restype = ctypes.POINTER(_Data)
+    lib.pcp_load_tsv.argtypes = [ctypes.c_char_p]
+    lib.pcp_free.argtypes = [ctypes.POINTER(_Data)]
+    handle = lib.pcp_load_tsv(os.fsencode(str(filepath)))
+    if not handle:
+        raise MemoryError("pcp_load_tsv: out of memory")
+    try:
+        d = handle.contents
+        if d.status != 0:
+            raise ValueError(d.error.decode("utf-8", "replace"))
+        N, P, W, G, R = d.n_genomes, d.n_phams, d.words_per_row, d.n_genes, d.n_residues
+
+        def arr(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+
+        def strings(buf, offs, n, nbytes):
+            raw = ctypes.string_at(buf, nbytes)
+            off = np.ctypeslib.as_array(offs, shape=(n + 1,))
+            return [raw[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(n)]
+
+        return PackedGenomes(
+            names=strings(d.names, d.name_off, N, d.names_bytes),
+            pham_names=strings(d.pham_names, d.pham_name_off, P, d.pham_names_bytes),
+            n_genomes=N, n_phams=P, words_per_row=W, bitmap=arr(d.bitmap, N * W), nph=arr(d.nph, N), ngen=arr(d.ngen, N),
+            tlen=arr(d.tlen, N), gene_off=arr(d.gene_off, N + 1), gene_pham=arr(d.gene_pham, G), seq_off=arr(d.seq_off, G + 1),
+            residues=arr(d.residues, R)).validate()
+    finally:
+        lib.pcp_free(handle)

@@ -138,6 +138,33 @@ def main():
         manifest["files"][metric] = {"distance_lower_triangle": f_dist.name, "similarity_adjacency": f_sim.name,
                                      "aligner": "none" if not tag else "oracle (parasail absent)"}
         print(metric, "written")
+    # ---- the reference's whole pipeline (stage 3-6: clustering, sub-clustering, outputs) for one set metric ----
+    # Heatmap rendering needs kaleido (absent here), so the one name `draw_heatmap` is replaced in the imported
+    # pipeline module's namespace for this run; heatmaps are not part of the fixture.  Everything else
+    # (SymMatrix, clustering.py, file writers, the pipeline function itself) is the reference's own code.
+    import phamclust.scripts.phamclust as ref_pipeline_module
+    ref_pipeline_module.draw_heatmap = lambda *a, **k: None
+    import shutil, tempfile
+    from phamclust.scripts.phamclust import phamclust as ref_pipeline
+    pipe_dir = HERE / "pipeline_jc"
+    if pipe_dir.exists():
+        shutil.rmtree(pipe_dir)
+    pipe_dir.mkdir()
+    with tempfile.TemporaryDirectory() as tmp:
+        out = pathlib.Path(tmp) / "out"; out.mkdir()
+        ref_pipeline(infile=tsv, outdir=out, is_genome_dir=False, metric="jc", nr_distance=round(1.0 - 0.75, 6),
+                     nr_linkage="complete", clu_distance=round(1.0 - 0.25, 6), clu_linkage="average",
+                     sub_distance=round(1.0 - 0.6, 6), sub_linkage="single", k_min=3, no_sub=False,
+                     colors=["red", "yellow", "green"], midpoint=0.5, cpus=1, rm_tmp=False, debug=False)
+        tree = {}
+        for path in sorted(out.rglob("*")):
+            rel = path.relative_to(out).as_posix()
+            if path.is_file() and ".tmp/01_genomes" not in rel and not rel.endswith((".svg", ".html", ".log")):
+                tree[rel] = path.read_text() if path.suffix == ".tsv" else None
+        md5 = [p.name for p in out.iterdir() if p.name.endswith(".tmp")][0]
+        (pipe_dir / "tree.json").write_text(json.dumps({"md5_tmp_dir": md5, "k_min": 3, "files": tree}, indent=0) + "\n")
+    manifest["pipeline"] = {"metric": "jc", "fixture": "pipeline_jc/tree.json", "note": "reference scripts/phamclust.py:phamclust() run "
+                            "with draw_heatmap disabled (kaleido absent); .tsv contents and the file tree are recorded"}
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1) + "\n")
 
 
