@@ -367,15 +367,14 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     uint32_t pw[ND];
     load_prof(a, pw);
 
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
+    // One row step.  `a`/`pw` are this step's row code and profile strip; `a_nxt`/`pw_nxt` receive the next step's.
+    auto step = [&](int t, int a, const uint32_t (&pw)[ND], int& a_nxt, uint32_t (&pw_nxt)[ND]) {
         if (((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         asm volatile("s_nop 1" ::: "memory");        // VALU (asm, previous step) -> DPP read: 2 wait states
         // the DPP shift must run with every lane active (a masked-off source lane reads as 0), so it is
         // computed unconditionally and selected afterwards -- never inside the branch of a ?:
         const int a_left = __builtin_amdgcn_mov_dpp(a, 0x138, 0xf, 0xf, true);
-        const int a_nxt = is_head ? e_nxt : a_left;
-        uint32_t pw_nxt[ND];
+        a_nxt = is_head ? e_nxt : a_left;
         load_prof(a_nxt, pw_nxt);
         e_nxt = in_seg ? (int)ring[ring_lane + ((t + 2) & (PC_WIN - 1))] : 0;
         int Hol = __builtin_amdgcn_mov_dpp(Hou[W - 1], 0x138, 0xf, 0xf, true);
@@ -406,9 +405,14 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
             res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
             out_r += nseg;
         }
-        a = a_nxt;
-#pragma unroll
-        for (int q = 0; q < ND; ++q) pw[q] = pw_nxt[q];
+    };
+    // two steps per iteration with the (code, strip) register sets swapping roles: no copies.  An odd T runs one
+    // extra step past the end of every stream (idle entries: no flags, no output).
+    int a2 = 0; uint32_t pw2[ND];
+#pragma unroll 1
+    for (int t = 0; t < T; t += 2) {
+        step(t, a, pw, a2, pw2);
+        step(t + 1, a2, pw2, a, pw);
     }
 }
 
