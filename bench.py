@@ -84,12 +84,15 @@ def main():
     from phamclust_amd.distributed import fill_distributed
     from phamclust_amd.synth import synth_packed
 
-    build.build_all()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if local_rank == 0:
+        build.build_all()                 # no-op when the in-tree libraries are current; one rank only
+    if world > 1:
+        dist.barrier()
 
     packed = synth_packed(a.genomes, a.phams)
     ctx = hip.Context(local_rank)
