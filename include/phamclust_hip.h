@@ -39,7 +39,9 @@ typedef enum {
 } pc_status;
 
 /* metric ids follow the order of the reference's METRICS dict (cli.py:30-35) */
-typedef enum { PC_GCS = 0, PC_JC = 1, PC_POCP = 2, PC_AF = 3, PC_AAI = 4, PC_PEQ = 5 } pc_metric;
+typedef enum { PC_GCS = 0, PC_JC = 1, PC_POCP = 2, PC_AF = 3, PC_AAI = 4, PC_PEQ = 5,
+               PC_AAI_PPOS = 6   /* average_aminoacid_identity(..., ppos=True), metrics.py:218-220: not a METRICS entry, no CLI route */
+} pc_metric;
 
 typedef struct pc_ctx pc_ctx;
 

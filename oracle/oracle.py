@@ -20,7 +20,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpc_oracle.so")
-METRIC_IDS = {"gcs": 0, "jc": 1, "pocp": 2, "af": 3, "aai": 4, "peq": 5}
+METRIC_IDS = {"gcs": 0, "jc": 1, "pocp": 2, "af": 3, "aai": 4, "peq": 5, "aai_ppos": 6}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _i32p = ctypes.POINTER(ctypes.c_int32)

@@ -299,7 +299,7 @@ extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? 
 // Step 5 of the plan: launch the alignment kernels for every class that has tasks.  Classes are
 // independent (disjoint result slots), so their launches are spread over the caller's stream and
 // three auxiliary streams: the drain of one class overlaps the next one's start.
-static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats) {
+static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats, int ppos) {
     const int ncls = (int)c->cls_variant.size();
     std::vector<int> order;
     for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
@@ -308,20 +308,22 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
         return nx != ny ? nx > ny : x < y;
     });
     if (order.empty()) return PC_OK;
+    // scratch of the general kernel: sized once for the longest column gene that will use it (never re-allocated
+    // between launches)
+    size_t sbytes = 0;
+    for (int i : order) if (ppos || c->cls_variant[i] < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(c->cls_max_lb[i]));
+    if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     PC_HIP(hipEventRecord(c->aux_ev[3], st));
     for (int k = 0; k < 3; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[3], 0));
     int slot = 0;
     for (int i : order) {
         const int nt = (int)(task_begin[i + 1] - task_begin[i]);
-        void* scratch = nullptr; size_t sbytes = 0;
-        hipStream_t ls = slot == 0 ? st : c->aux[slot - 1];
-        if (c->cls_variant[i] < 0) {
-            sbytes = pc_nw_fallback_scratch_bytes(c->cls_max_lb[i]);
-            int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc;
-            scratch = c->b_scratch.p;
-        }
-        int rc = pc_launch_nw(c->cls_variant[i], c->dev, c->b_tasks.as<PcTask>() + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
-                              c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, c->cls_max_lb[i], ls);
+        const int variant = ppos ? -1 : c->cls_variant[i];        // percent-positives: general kernel (rare, no CLI route)
+        // launches that use the one scratch slab stay in order on the caller's stream
+        hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
+        int rc = pc_launch_nw(variant, c->dev, c->b_tasks.as<PcTask>() + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
+                              c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
+                              variant < 0 ? c->b_scratch.cap : 0, c->cls_max_lb[i], ppos, ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) & 3;
@@ -335,7 +337,9 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
 
 static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
     if (!c || !c->uploaded) { pc_set_error("fill: upload first"); return PC_ERR_STATE; }
-    if (metric < PC_GCS || metric > PC_PEQ) { pc_set_error("fill: metric %d", metric); return PC_ERR_ARG; }
+    if (metric < PC_GCS || metric > PC_AAI_PPOS) { pc_set_error("fill: metric %d", metric); return PC_ERR_ARG; }
+    const int ppos = metric == PC_AAI_PPOS;
+    if (ppos) metric = PC_AAI;
     if (!out) { pc_set_error("fill: out is NULL"); return PC_ERR_ARG; }
     int rc = set_device(c); if (rc != PC_OK) return rc;
     if (!st) st = c->stream;
@@ -412,7 +416,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         PC_HIP(hipEventRecord(c->ev[1], st));
         // 5 K4
         std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
-        if ((rc = run_align_classes(c, tb.data(), st, &local))) return rc;
+        if ((rc = run_align_classes(c, tb.data(), st, &local, ppos))) return rc;
         PC_HIP(hipEventRecord(c->ev[2], st));
         // 6 REDUCE
         a.res = c->b_res.as<uint2>(); a.out = out;
@@ -539,7 +543,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
             scratch = c->b_scratch.p;
         }
         rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[cl], nt, c->b_bucket_row.as<int32_t>(),
-                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], st);
+                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], 0, st);
         if (rc != PC_OK) { cleanup(); return rc; }
     }
     (void)hipEventRecord(c->ev[2], st);

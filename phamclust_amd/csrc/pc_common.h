@@ -90,5 +90,5 @@ int pc_nw_num_variants();
 int pc_nw_variant_w(int v);                       // columns per lane of variant v
 int pc_nw_choose_variant(int lb);                 // -1: general fallback
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, hipStream_t st);
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, hipStream_t st);
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

@@ -75,7 +75,7 @@ __device__ __forceinline__ PcCell pc_cell(int Hol, int El, uint32_t SHl, uint32_
 __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __restrict__ tasks, int ntasks,
                                                    const int32_t* __restrict__ bucket_row,
                                                    const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res,
-                                                   int4* __restrict__ scratch, int64_t scratch_stride) {
+                                                   int4* __restrict__ scratch, int64_t scratch_stride, int ppos) {
     __shared__ int8_t tab[24][24];
     for (int i = threadIdx.x; i < 576; i += 64) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
     __syncthreads();
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
                 const int bj = bp[j];
                 const int4 up = sc[(int64_t)j * 64 + lane];
                 const PcCell c = pc_cell(Hol, El, SHl, SEl, up.x, up.y, (uint32_t)up.z, (uint32_t)up.w, Hod, SHd,
-                                         trow[min(bj, 23)], ai == bj);
+                                         trow[min(bj, 23)], ai == bj || (ppos && trow[min(bj, 23)] > PC_OPEN));   // ppos: '+' columns count too
                 if (live) sc[(int64_t)j * 64 + lane] = make_int4(c.Ho, c.F, (int)c.SH, (int)c.SF);
                 Hod = up.x; SHd = (uint32_t)up.z;
                 Hol = c.Ho; El = c.E; SHl = c.SH; SEl = c.SE;
@@ -463,8 +463,9 @@ size_t pc_nw_fallback_scratch_bytes(int max_lb) {
 }
 
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, hipStream_t st) {
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
+    if (variant >= 0 && ppos) { pc_set_error("pc_launch_nw: ppos runs on the general kernel only"); return PC_ERR_ARG; }
     if (variant >= 0) {
         if (variant >= g_num_variants || max_lb > 64 * g_variant_w[variant]) {
             pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
@@ -484,7 +485,7 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
     if (blocks > 1024) blocks = 1024;
     if (blocks > (size_t)ntasks) blocks = (size_t)ntasks;
     hipLaunchKernelGGL(k_nw_general, dim3((unsigned)blocks), dim3(64), 0, st, d, tasks, ntasks, bucket_row, bucket_dest, res,
-                       (int4*)scratch, (int64_t)(per_block / sizeof(int4)));
+                       (int4*)scratch, (int64_t)(per_block / sizeof(int4)), ppos);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_nw_general launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;

@@ -44,9 +44,8 @@ def alignment_fraction(source, target, as_distance=False):
 def average_aminoacid_identity(source, target, ppos=False, as_distance=False):
     """Length-weighted identity of best-matching genes in shared phams, global alignment
     BLOSUM62 11/1 (reference metrics.py:178-232)."""
-    if ppos:
-        raise NotImplementedError("ppos=True (percent positives) is not on the accelerated path; "
-                                  "no CLI route sets it (reference cli.py has no such flag)")
+    if ppos:                                      # '+' columns (matrix score > 0) count as well (metrics.py:218-220)
+        return _pairwise("aai_ppos", source, target, as_distance)
     return _pairwise("aai", source, target, as_distance)
 
 

@@ -248,6 +248,24 @@ def test_shard_and_assemble_single_gpu(gpu_ctx, native_built):
         gpu_ctx.set_shard(0, 1)
 
 
+def test_aai_percent_positives(gpu_ctx, native_built, small_genomes, small_packed):
+    """ppos=True (metrics.py:218-220): '+' columns count too.  Pairwise callable, bulk fill and both oracle
+    restatements agree."""
+    from phamclust_amd.metrics import average_aminoacid_identity
+    O = _oracle()
+    got = gpu_ctx.upload(small_packed).fill("aai_ppos", as_distance=False)
+    plain = gpu_ctx.fill("aai", as_distance=False)
+    n = small_packed.n_genomes
+    want_c = np.array([O.pair(small_packed, "aai_ppos", s, t, as_distance=False) for s in range(n) for t in range(s + 1, n)])
+    assert np.array_equal(got, want_c)
+    assert (got >= plain).all() and (got > plain).any()
+    for s, t in ((0, 5), (3, 17), (16, 18), (20, 22)):
+        py = O.py_aai(small_genomes[s], small_genomes[t], ppos=True)
+        assert py == O.pair(small_packed, "aai_ppos", s, t, as_distance=False)
+        assert average_aminoacid_identity(small_genomes[s], small_genomes[t], ppos=True) == py
+        assert average_aminoacid_identity(small_genomes[s], small_genomes[t], True, True) == O.py_aai(small_genomes[s], small_genomes[t], True, True)
+
+
 def test_matrix_de_novo_drop_in(native_built, small_genomes):
     """The reference-shaped entry point: matrix_de_novo(genomes, METRICS[m], cpus)."""
     from phamclust_amd.cli import METRICS
