@@ -1,4 +1,6 @@
-from phamclust_amd.scripts.phamclust import main
+"""``python -m phamclust_amd <infile> <outdir> [flags]`` runs the pipeline."""
+import sys
 
-if __name__ == "__main__":
-    main()
+from phamclust_amd.scripts import phamclust as pipeline
+
+sys.exit(pipeline.main())

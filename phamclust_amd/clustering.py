@@ -1,28 +1,28 @@
-"""Hierarchical clustering of a distance ``SymMatrix`` (reference clustering.py:4-51).
+"""Agglomerative clustering of a distance ``SymMatrix`` (the reference's clustering.py:4-51 contract).
 
-The clustering itself stays scikit-learn's ``AgglomerativeClustering`` on the precomputed
-matrix, exactly as in the reference; what changes is the hand-off: ``SymMatrix.to_ndarray``
-is one fancy-index of the dense array the GPU fill produced, not N^2 Python lookups.
+scikit-learn's ``AgglomerativeClustering`` on the precomputed matrix does the work, as in the reference.
+The hand-off is what differs: ``to_ndarray()`` is one fancy-index of the array the GPU fill produced, and the
+members of each label are gathered with numpy instead of per-node Python dict traffic.
 """
 
+import numpy as np
 from sklearn.cluster import AgglomerativeClustering
 
 
 def hierarchical_clustering(matrix, linkage, eps=None, n_clusters=None):
-    """Cluster the nodes of a distance matrix; returns sub-matrices, largest first.
-    ``eps`` (distance threshold) and ``n_clusters`` are mutually exclusive."""
+    """Sub-matrices of the clusters, largest first.  Give either ``eps`` (distance threshold) or ``n_clusters``."""
     if len(matrix) == 1:
         return [matrix]
     if not matrix.is_distance:
         raise ValueError("matrix must be a distance matrix")
-    dist = matrix.to_ndarray()
     if eps is None and not n_clusters:
         raise ValueError("need either threshold or n_clusters to proceed")
     if eps and n_clusters:
         raise ValueError("threshold and n_clusters are mutually exclusive")
-    model = AgglomerativeClustering(metric="precomputed", linkage=linkage, distance_threshold=eps, n_clusters=n_clusters)
-    members = dict()
-    for node, label in zip(matrix.nodes, model.fit_predict(dist)):
-        members.setdefault(label, set()).add(node)
-    clusters = [matrix.extract_submatrix(list(nodes)) for nodes in members.values()]
-    return sorted(clusters, reverse=True)
+    labels = AgglomerativeClustering(metric="precomputed", linkage=linkage, distance_threshold=eps,
+                                     n_clusters=n_clusters).fit_predict(matrix.to_ndarray())
+    nodes = np.asarray(matrix.nodes, dtype=object)
+    # clusters in order of first appearance of their label, as a dict keyed by label would give
+    _, first = np.unique(labels, return_index=True)
+    parts = [matrix.extract_submatrix(nodes[labels == labels[i]].tolist()) for i in sorted(first)]
+    return sorted(parts, reverse=True)

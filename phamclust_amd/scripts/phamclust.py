@@ -1,19 +1,22 @@
-"""The phamclust pipeline around the GPU matrix fill (reference scripts/phamclust.py:140-545).
+"""The pipeline around the GPU matrix fill.
 
-Same stages, file names and formats as the reference so that outputs and the on-disk cache
-interoperate: load genomes -> sort by name -> md5 of the FASTA text -> ``{md5}.tmp`` ->
-``01_genomes/*.fasta`` -> ``02_distmats/{metric}_distance_matrix.tsv`` (lower triangle; reused when
-present) -> integrity check -> three rounds of hierarchical clustering -> per-cluster directories,
-similarity matrices, heatmaps (when plotly is available) -> pairwise similarity outputs.
-The only change is stage 2: ``matrix_de_novo`` runs on the GPU.
+What it must stay compatible with is the reference's on-disk contract (scripts/phamclust.py:140-473), so that
+caches and results interoperate: genomes sorted by name; cache directory ``<outdir>/<md5 of the FASTA text>.tmp``
+holding ``01_genomes/<name>.fasta`` and ``02_distmats/<metric>_distance_matrix.tsv`` (lower triangle, reused when
+present); three agglomerative passes (pre-group at ``nr``, cluster the group medoids at ``clu``, sub-cluster at
+``sub``); ``cluster_<i>/`` (largest first) with ``genomes/*.faa``, ``<metric>_similarity.tsv``,
+``subcluster_<j>_similarity.tsv`` and two heatmaps; ``singletons/genomes``; ``pairwise_<metric>_similarities.tsv`` and
+``pairwise_<metric>_adjacency.tsv``.  Stage 2 is the only thing that changed: it is one GPU call.
 """
 
-import datetime
 import hashlib
 import logging
 import pathlib
 import shutil
 import sys
+import time
+
+import numpy as np
 
 from phamclust_amd.cli import METRICS, parse_args
 from phamclust_amd.clustering import hierarchical_clustering
@@ -23,290 +26,233 @@ from phamclust_amd.matrix import matrix_de_novo, matrix_from_squareform, matrix_
 
 LOG_STR_FMT = "phamclust: %(asctime)s.%(msecs)03d: %(levelname)s: %(message)s"
 LOG_TIME_FMT = "%H:%M:%S"
-FASTA_SUFFIXES = (".fasta", ".faa", ".fa")
+FASTA_SUFFIXES = {".fasta", ".faa", ".fa"}
+log = logging.getLogger()
 
 
+# ---- input ---------------------------------------------------------------------------------
 def load_genomes_from_tsv(filepath):
-    """2- or 3-column TSV -> list[Genome] in first-appearance order (2 columns: translation "M")."""
-    genomes = dict()
-    with open(filepath, "r") as handle:
-        for line in handle:
-            row = line.rstrip().split("\t")
-            if len(row) == 3:
-                name, pham, translation = row
-            elif len(row) == 2:
-                (name, pham), translation = row, "M"
-            else:
+    """Rows ``genome, pham[, translation]``; a missing translation is "M"; genomes in first-seen order."""
+    found = {}
+    with open(filepath) as handle:
+        for number, line in enumerate(handle, start=1):
+            fields = line.rstrip().split("\t")
+            if len(fields) == 2:
+                fields.append("M")
+            if len(fields) != 3:
                 raise ValueError("input file must either 2 or 3 columns")
-            if name not in genomes:
-                genomes[name] = Genome(name)
-            genomes[name].add(pham, translation)
-    return list(genomes.values())
+            name, pham, translation = fields
+            genome = found.get(name)
+            if genome is None:
+                genome = found[name] = Genome(name)
+            genome.add(pham, translation)
+    return list(found.values())
 
 
 def load_genomes_from_fasta_dir(filepath):
-    """One FASTA per genome, headers ``>name=..|pham=..|n=..``; the file stem names the genome."""
-    genomes = dict()
-    for f in filepath.iterdir():
-        if f.suffix not in FASTA_SUFFIXES:
-            logging.debug(f"{f} does not appear to be FASTA - skipping")
+    """One FASTA file per genome (stem = genome name; headers carry ``pham=``)."""
+    found = {}
+    for path in filepath.iterdir():
+        if path.suffix not in FASTA_SUFFIXES or path.is_dir():
+            log.debug(f"skipping {path}")
             continue
-        if f.is_dir():
-            logging.debug(f"{f} appears to be a directory - skipping")
-            continue
-        if f.stem in genomes:
-            raise ValueError(f"duplicate genome name detected {f.stem}")
-        genomes[f.stem] = Genome(f.stem)
-        genomes[f.stem].load(f)
-    return list(genomes.values())
+        if path.stem in found:
+            raise ValueError(f"duplicate genome name detected {path.stem}")
+        found[path.stem] = genome = Genome(path.stem)
+        genome.load(path)
+    return list(found.values())
 
 
 def _hash_genomes(genomes):
-    """md5 over the FASTA text of the genomes in the given (name-sorted) order."""
-    digest = hashlib.new("md5")
+    """md5 of the concatenated FASTA text, genomes in the order given (the cache key)."""
+    md5 = hashlib.md5()
     for genome in genomes:
-        digest.update(str(genome).encode())
-    return digest.hexdigest()
+        md5.update(str(genome).encode())
+    return md5.hexdigest()
 
 
 def check_matrix_integrity(matrix):
-    """(edge-count error, diagonal-sum error, unfilled edges) - all zero for a sound matrix
-    (reference scripts/phamclust.py:109-137).  The array-backed matrix always holds N(N-1)/2 edge slots,
-    so the first term can only be zero; unset slots (NaN) are what can still go wrong."""
-    import numpy as np
-    n = len(matrix)
+    """(edge-count error, diagonal-sum error, unfilled slots); all zero for a usable matrix.  The array-backed
+    matrix cannot have the wrong number of edges, so the first term is always 0 here."""
     full = matrix.to_ndarray()
-    upper = full[np.triu_indices(n, k=0)]
-    unfilled = int(np.isnan(upper).sum())
-    diag_sum = float(np.nansum(full.diagonal()))
-    return 0, diag_sum - (1.0 - matrix.is_distance) * n, unfilled
+    upper = full[np.triu_indices(len(matrix))]
+    return 0, float(np.nansum(full.diagonal())) - (0.0 if matrix.is_distance else float(len(matrix))), int(np.isnan(upper).sum())
 
 
-def _mkdir(path):
-    if not path.is_dir():
-        path.mkdir()
-    return path
+# ---- the run -----------------------------------------------------------------------------------
+class _Run:
+    def __init__(self, outdir, metric, colors, midpoint):
+        self.outdir, self.metric, self.colors, self.midpoint = outdir, metric, colors, midpoint
+        self.genomes, self.by_name, self.cache, self.stage = [], {}, None, None
 
+    @staticmethod
+    def _dir(path, fresh=False):
+        if fresh and path.is_dir():
+            shutil.rmtree(path)
+        path.mkdir(exist_ok=True)
+        return path
 
-def _fresh_dir(path):
-    if path.is_dir():
-        shutil.rmtree(path)
-    path.mkdir()
-    return path
+    def banner(self, number, title):
+        log.info(f"--- {number}: {title} ---")
+
+    # 1
+    def read(self, infile, is_genome_dir):
+        self.banner(1, "genomes")
+        self.genomes = load_genomes_from_fasta_dir(infile) if is_genome_dir else load_genomes_from_tsv(infile)
+        self.genomes.sort(key=lambda g: g.name)
+        self.by_name = {g.name: g for g in self.genomes}
+        digest = _hash_genomes(self.genomes)
+        self.cache = self._dir(self.outdir / f"{digest}.tmp")
+        log.info(f"{len(self.genomes)} genomes, md5 {digest}, cache {self.cache.name}")
+        stash = self._dir(self.cache / "01_genomes")
+        for genome in self.genomes:
+            target = stash / f"{genome.name}.fasta"
+            if not target.is_file():
+                genome.save(target)
+
+    # 2
+    def distances(self, cpus):
+        self.banner(2, f"{self.metric} distance matrix")
+        cached = self._dir(self.cache / "02_distmats") / f"{self.metric}_distance_matrix.tsv"
+        t0 = time.perf_counter()
+        if cached.is_file():
+            matrix = matrix_from_squareform(cached)
+            log.info(f"read cached matrix in {time.perf_counter() - t0:.3f} s")
+        else:
+            matrix = matrix_de_novo(self.genomes, METRICS[self.metric], cpus)
+            log.info(f"filled {len(matrix)} x {len(matrix)} matrix on the GPU in {time.perf_counter() - t0:.3f} s (incl. packing)")
+            matrix_to_squareform(matrix, cached, lower_triangle=True)
+        if not matrix.is_distance:
+            matrix.invert()
+        edges, diagonal, unfilled = check_matrix_integrity(matrix)
+        if edges or diagonal or unfilled:
+            log.error(f"matrix failed integrity checks: edge count off by {edges}, diagonal off by {diagonal}, {unfilled} unfilled")
+            print("matrix validation failed - check log for details")
+            sys.exit(1)
+        return matrix
+
+    # 3
+    def clusters(self, matrix, nr, clu):
+        self.banner(3, "clusters")
+        groups = hierarchical_clustering(matrix, eps=nr[0], linkage=nr[1])          # near-identical genomes
+        by_medoid = {group.medoid[0]: group for group in groups}
+        medoids = matrix.extract_submatrix(list(by_medoid))
+        merged = []
+        for cluster in hierarchical_clustering(medoids, eps=clu[0], linkage=clu[1]):
+            members = [node for medoid in cluster.nodes for node in by_medoid[medoid].nodes]
+            merged.append(matrix.extract_submatrix(members))
+        multi = sorted((m for m in merged if len(m) > 1), reverse=True)
+        single = [m for m in merged if len(m) == 1]
+        log.info(f"{len(groups)} pre-groups -> {len(multi)} clusters + {len(single)} singletons")
+        return multi, single
+
+    # 4
+    def write_cluster(self, number, cluster, sub, k_min, no_sub):
+        root = self._dir(self.stage / f"cluster_{number}", fresh=True)
+        faa = self._dir(root / "genomes")
+        members = set(cluster.nodes)
+        for genome in self.genomes:
+            if genome.name in members:
+                genome.save(faa / f"{genome.name}.faa")
+        if no_sub or len(cluster) < k_min:
+            cluster.reorder()
+        else:
+            order = []
+            parts = sorted(hierarchical_clustering(cluster, eps=sub[0], linkage=sub[1]), reverse=True)
+            for j, part in enumerate(parts, start=1):
+                if len(part) > 2:
+                    part.reorder()
+                order += part.nodes
+                matrix_to_squareform(part.invert(), root / f"subcluster_{j}_similarity.tsv")
+            cluster.reorder(order)
+        matrix_to_squareform(cluster.invert(), root / f"{self.metric}_similarity.tsv")
+        for suffix in ("svg", "html"):
+            draw_heatmap(cluster, colors=self.colors, midpoint=self.midpoint, filename=root / f"{self.metric}_heatmap.{suffix}")
+
+    # 5 + 6
+    def finish(self, matrix, multi, single, clu_distance, rm_tmp):
+        self.banner(5, "dataset outputs")
+        matrix.reorder([n for m in multi for n in m.nodes] + [n for m in single for n in m.nodes])
+        matrix.invert()
+        if len(matrix) > 1500:
+            log.info("matrix too large for a dataset heatmap")
+        else:
+            for suffix in ("html", "svg"):
+                draw_heatmap(matrix, colors=self.colors, midpoint=1.0 - clu_distance,
+                             filename=self.stage / f"{self.metric}_heatmap.{suffix}")
+        for old in self.outdir.iterdir():                      # clear earlier results, keep cache and log
+            if old.name == self.cache.name or old.suffix == ".log":
+                continue
+            shutil.rmtree(old) if old.is_dir() else old.unlink()
+        matrix_to_squareform(matrix, self.outdir / f"pairwise_{self.metric}_similarities.tsv")
+        matrix_to_adjacency(matrix, self.outdir / f"pairwise_{self.metric}_adjacency.tsv", skip_zero=True)
+        shutil.copytree(self.stage, self.outdir, dirs_exist_ok=True)
+        shutil.rmtree(self.stage)
+        if rm_tmp:
+            shutil.rmtree(self.cache)
 
 
 def phamclust(infile, outdir, is_genome_dir, metric, nr_distance, nr_linkage, clu_distance, clu_linkage, sub_distance,
               sub_linkage, k_min, no_sub, colors, midpoint, cpus, rm_tmp, debug):
-    if nr_distance >= clu_distance:
+    """Same signature as the reference's ``phamclust()`` (distances, not similarities, for the thresholds)."""
+    if nr_distance >= clu_distance:          # pre-grouping must be tighter than clustering, else switch it off
         nr_distance = 0.0
-    log = logging.info
-    log("=======================")
-    log(" 0: runtime parameters ")
-    log("=======================")
-    for key, value in (("infile", infile), ("outdir", outdir), ("debug", debug), ("subcluster", not no_sub),
-                       ("remove tmp", rm_tmp), ("sub dist", sub_distance), ("sub link", sub_linkage),
-                       ("clu dist", clu_distance), ("clu link", clu_linkage), ("nr dist", nr_distance),
-                       ("nr link", nr_linkage), ("metric", metric), ("cpus", cpus), ("colors", ",".join(colors)),
-                       ("midpoint", midpoint)):
-        log(f"{key + ':':<11} {value}")
+    settings = dict(infile=infile, outdir=outdir, metric=metric, nr=(nr_distance, nr_linkage), clu=(clu_distance, clu_linkage),
+                    sub=(sub_distance, sub_linkage), k_min=k_min, subcluster=not no_sub, colors=",".join(colors),
+                    midpoint=midpoint, cpus=cpus, remove_tmp=rm_tmp, debug=debug)
+    log.info("--- 0: settings ---")
+    for key, value in settings.items():
+        log.info(f"{key:<11}{value}")
+    run = _Run(outdir, metric, colors, midpoint)
+    run.read(infile, is_genome_dir)
+    matrix = run.distances(cpus)
+    multi, single = run.clusters(matrix, (nr_distance, nr_linkage), (clu_distance, clu_linkage))
+    run.banner(4, "sub-clusters")
+    run.stage = run._dir(run.cache / "03_clusters")
+    for number, cluster in enumerate(multi, start=1):
+        log.info(f"cluster {number}: {len(cluster)} genomes")
+        run.write_cluster(number, cluster, (sub_distance, sub_linkage), k_min, no_sub)
+    if single:
+        lone = run._dir(run._dir(run.stage / "singletons", fresh=True) / "genomes")
+        for one in single:
+            name = one.nodes[0]
+            run.by_name[name].save(lone / f"{name}.faa")
+    run.finish(matrix, multi, single, clu_distance, rm_tmp)
 
-    log("====================")
-    log(" 1: parsing genomes ")
-    log("====================")
-    if is_genome_dir:
-        genomes = load_genomes_from_fasta_dir(infile)
-        log(f"loaded {len(genomes)} genomes from input directory")
-    else:
-        genomes = load_genomes_from_tsv(infile)
-        log(f"loaded {len(genomes)} genomes from input TSV")
-    genomes.sort(key=lambda g: g.name)
-    by_name = {g.name: g for g in genomes}
-    hashsum = _hash_genomes(genomes)
-    log(f"md5 hashsum is {hashsum}")
-    tmpdir = _mkdir(outdir.joinpath(f"{hashsum}.tmp"))
-    log(f"using temp directory {tmpdir.name}")
-    tmp_genomes = _mkdir(tmpdir.joinpath("01_genomes"))
-    for genome in genomes:
-        fasta = tmp_genomes.joinpath(f"{genome.name}.fasta")
-        if not fasta.is_file():
-            genome.save(fasta)
-    log(f"genomes stashed in {tmpdir.name}/{tmp_genomes.name}")
 
-    log("==========================")
-    log(" 2: build distance matrix ")
-    log("==========================")
-    log(f"selected metric: {metric}")
-    tmp_distmats = _mkdir(tmpdir.joinpath("02_distmats"))
-    dist_file = tmp_distmats.joinpath(f"{metric}_distance_matrix.tsv")
-    start = datetime.datetime.now()
-    if not dist_file.is_file():
-        log("cached distance matrix not found - computing de novo")
-        dist_mat = matrix_de_novo(genomes, METRICS[metric], cpus)
-        log(f"computed distance matrix in {datetime.datetime.now() - start}")
-        log("caching distance matrix so it can be re-used")
-        matrix_to_squareform(dist_mat, dist_file, lower_triangle=True)
-    else:
-        log("found cached distance matrix - importing it")
-        dist_mat = matrix_from_squareform(dist_file)
-        log(f"loaded distance matrix in {datetime.datetime.now() - start}")
-    if not dist_mat.is_distance:
-        log("matrix is not a distance matrix - flipping it")
-        dist_mat.invert()
-    status = check_matrix_integrity(dist_mat)
-    if not any(status):
-        log("matrix passed all integrity checks")
-    else:
-        logging.error("matrix failed the following integrity check(s):")
-        if status[0]:
-            logging.error(f"found {abs(status[0])} too {'many' if status[0] > 0 else 'few'} edges")
-        if status[1] != 0:
-            logging.error(f"diagonal sum is off by {status[1]}")
-        if status[2] != 0:
-            logging.error(f"found {status[2]} unfilled edges")
-        print("matrix validation failed - check log for details")
+def _colors(text):
+    colors = text.split(",")
+    if not 2 <= len(colors) <= 3:
+        log.error(f"expected either two or three colors, got {len(colors)}")
         sys.exit(1)
-
-    log("====================")
-    log(" 3: cluster genomes ")
-    log("====================")
-    log(f"grouping highly redundant genomes with distance <= {nr_distance} by {nr_linkage} linkage")
-    seeds = hierarchical_clustering(dist_mat, eps=nr_distance, linkage=nr_linkage)
-    seed_map = {m.medoid[0]: m for m in seeds}
-    repr_mat = dist_mat.extract_submatrix(list(seed_map.keys()))
-    log(f"found {len(repr_mat)} groups of similar genomes")
-    log(f"clustering non-redundant genomes with distance <= {clu_distance} by {clu_linkage} linkage")
-    clu_mats = hierarchical_clustering(repr_mat, eps=clu_distance, linkage=clu_linkage)
-    for i, clu_mat in enumerate(clu_mats):
-        nodes = []
-        for representative in clu_mat.nodes:
-            nodes.extend(seed_map[representative].nodes)
-        clu_mats[i] = dist_mat.extract_submatrix(nodes)
-    single_mats = [m for m in clu_mats if len(m) == 1]
-    clu_mats = [m for m in clu_mats if len(m) > 1]
-    log(f"found {len(clu_mats)} clusters and {len(single_mats)} singletons")
-    tmp_clusters = _mkdir(tmpdir.joinpath("03_clusters"))
-
-    log("========================")
-    log(" 4: sub-cluster genomes ")
-    log("========================")
-    for i, clu_mat in enumerate(sorted(clu_mats, reverse=True)):
-        log(f"cluster {i + 1} has {len(clu_mat)} nodes")
-        cluster_dir = _fresh_dir(tmp_clusters.joinpath(f"cluster_{i + 1}"))
-        genome_dir = _mkdir(cluster_dir.joinpath("genomes"))
-        members = set(clu_mat.nodes)
-        for genome in genomes:
-            if genome.name in members:
-                genome.save(genome_dir.joinpath(f"{genome.name}.faa"))
-        matfile = cluster_dir.joinpath(f"{metric}_similarity.tsv")
-        if no_sub or len(clu_mat) < k_min:
-            logging.debug(f"not sub-clustering {len(clu_mat)} genomes")
-            clu_mat.reorder()
-        else:
-            order = []
-            sub_mats = sorted(hierarchical_clustering(clu_mat, eps=sub_distance, linkage=sub_linkage), reverse=True)
-            for j, sub_mat in enumerate(sub_mats):
-                if len(sub_mat) > 2:
-                    sub_mat.reorder()
-                order.extend(sub_mat.nodes)
-                sub_mat.invert()
-                matrix_to_squareform(sub_mat, cluster_dir.joinpath(f"subcluster_{j + 1}_similarity.tsv"))
-            clu_mat.reorder(order)
-        clu_mat.invert()
-        matrix_to_squareform(clu_mat, matfile)
-        draw_heatmap(clu_mat, colors=colors, midpoint=midpoint, filename=cluster_dir.joinpath(f"{metric}_heatmap.svg"))
-        draw_heatmap(clu_mat, colors=colors, midpoint=midpoint, filename=cluster_dir.joinpath(f"{metric}_heatmap.html"))
-
-    if single_mats:
-        genome_dir = _mkdir(_fresh_dir(tmp_clusters.joinpath("singletons")).joinpath("genomes"))
-        for single in single_mats:
-            node = single.nodes[0]
-            by_name[node].save(genome_dir.joinpath(f"{node}.faa"))
-
-    log("========================")
-    log(" 5: draw dataset heatmap")
-    log("========================")
-    log("putting matrix in cluster order")
-    order = []
-    for clu_mat in sorted(clu_mats, reverse=True):
-        order.extend(clu_mat.nodes)
-    for single in single_mats:
-        order.extend(single.nodes)
-    dist_mat.reorder(order)
-    log("cast to similarity matrix for easier visualization")
-    dist_mat.invert()
-    if len(dist_mat) > 1500:
-        log("full pairwise matrix is too large to visualize")
-    else:
-        for suffix in ("html", "svg"):
-            target = tmp_clusters.joinpath(f"{metric}_heatmap.{suffix}")
-            log(f"drawing heatmap {suffix.upper()} and saving to {target}")
-            draw_heatmap(dist_mat, colors=colors, midpoint=1.0 - clu_distance, filename=target)
-
-    log("========================")
-    log(" 6: move output files   ")
-    log("========================")
-    log(f"removing contents from existing output directory {outdir}")
-    for fp in outdir.iterdir():
-        if fp.name == tmpdir.name or fp.suffix == ".log":
-            continue
-        if fp.is_file():
-            fp.unlink()
-        elif fp.is_dir():
-            shutil.rmtree(fp)
-        else:
-            logging.warning(f"skip removal of unknown filetype {fp}")
-    target = outdir.joinpath(f"pairwise_{metric}_similarities.tsv")
-    log(f"writing pairwise {metric} similarities to {target}")
-    matrix_to_squareform(dist_mat, target)
-    target = outdir.joinpath(f"pairwise_{metric}_adjacency.tsv")
-    log(f"writing pairwise {metric} adjacency to {target}")
-    matrix_to_adjacency(dist_mat, target, skip_zero=True)
-    log(f"moving output files from temporary directory to {outdir}")
-    shutil.copytree(tmp_clusters, outdir, dirs_exist_ok=True)
-    shutil.rmtree(tmp_clusters)
-    if rm_tmp:
-        log(f"cleaning up temporary files in {tmpdir}")
-        shutil.rmtree(tmpdir)
+    bad = [c for c in colors if c not in CSS_COLORS]
+    if bad:
+        log.error(f"unknown colors {bad}; valid colors: {' '.join(sorted(CSS_COLORS))}")
+        sys.exit(1)
+    if len(colors) == 2:
+        log.warning("2-color scale ignores `--heatmap-midpoint`")
+    return colors
 
 
 def main(argv=None):
     if argv is None and len(sys.argv) == 1:
         sys.argv.append("-h")
     args = parse_args(argv)
-    if args.genome_dir and not args.infile.is_dir():
-        print(f"genome directory '{args.infile}' does not exist")
+    if not (args.infile.is_dir() if args.genome_dir else args.infile.is_file()):
+        kind = "genome directory" if args.genome_dir else "input TSV"
+        print(f"{kind} '{args.infile}' does not exist")
         sys.exit(1)
-    if not args.genome_dir and not args.infile.is_file():
-        print(f"input TSV '{args.infile}' does not exist")
-        sys.exit(1)
-    if not args.outdir.is_dir():
-        args.outdir.mkdir(parents=True)
-    logging.basicConfig(filename=args.outdir.joinpath("phamclust.log"), filemode="w",
-                        level=logging.DEBUG if args.debug else logging.INFO, format=LOG_STR_FMT, datefmt=LOG_TIME_FMT,
-                        force=True)
-    logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
-
-    colors = args.heatmap_colors.split(",")
-    if not 2 <= len(colors) <= 3:
-        logging.error(f"expected either two or three colors, got {len(colors)}")
-        sys.exit(1)
-    if len(colors) == 2:
-        logging.warning("2-color scale ignores `--heatmap-midpoint`")
-    unknown = [c for c in colors if c not in CSS_COLORS]
-    if unknown:
-        for color in unknown:
-            logging.error(f"unknown color specified: '{color}'")
-        logging.error(f"got {len(unknown)} unrecognized colors")
-        logging.error("valid colors:")
-        logging.error(" ".join(sorted(CSS_COLORS)))
-        sys.exit(1)
-
+    args.outdir.mkdir(parents=True, exist_ok=True)
+    logging.basicConfig(filename=args.outdir / "phamclust.log", filemode="w", format=LOG_STR_FMT, datefmt=LOG_TIME_FMT,
+                        level=logging.DEBUG if args.debug else logging.INFO, force=True)
+    log.addHandler(logging.StreamHandler(sys.stdout))
+    as_distance = lambda similarity: round(1.0 - similarity, 6)          # noqa: E731
     phamclust(infile=args.infile, outdir=args.outdir, is_genome_dir=args.genome_dir, metric=args.metric,
-              nr_distance=round(1.0 - args.nr_thresh, 6), nr_linkage=args.nr_linkage,
-              clu_distance=round(1.0 - args.clu_thresh, 6), clu_linkage=args.clu_linkage,
-              sub_distance=round(1.0 - args.sub_thresh, 6), sub_linkage=args.sub_linkage,
-              k_min=max([1, args.k_min]), colors=colors, midpoint=round(args.heatmap_midpoint, 6), cpus=args.threads,
-              no_sub=args.no_sub, rm_tmp=args.remove_tmp, debug=args.debug)
+              nr_distance=as_distance(args.nr_thresh), nr_linkage=args.nr_linkage,
+              clu_distance=as_distance(args.clu_thresh), clu_linkage=args.clu_linkage,
+              sub_distance=as_distance(args.sub_thresh), sub_linkage=args.sub_linkage, k_min=max(1, args.k_min),
+              no_sub=args.no_sub, colors=_colors(args.heatmap_colors), midpoint=round(args.heatmap_midpoint, 6),
+              cpus=args.threads, rm_tmp=args.remove_tmp, debug=args.debug)
 
 
 if __name__ == "__main__":
