@@ -423,10 +423,12 @@ static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 int pc_nw_num_variants() { return g_num_variants; }
 int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
 
-// Variant for a column gene of lb residues.  Measured on MI355X (profiles/r01_e_variant_gcups.txt): time per
-// row step ~ W + 4.4 + 0.47 nseg cell-equivalents (15-instruction cells + per-step overhead that grows with the
-// number of segments: resets, stream refills), during which a wave retires nseg rows of lb cells -> minimise
-// (W + 4.4 + 0.47 nseg) / nseg over the variants whose 64*W columns cover lb.
+// Variant for a column gene of lb residues.  Least-squares fit to measured kernel-only GCUPS of every variant
+// over L = 60..1200 on MI355X (profiles/r01_l_variant_gcups.txt, mean error 2.3 %): time per row step
+// ~ (W + 1.02 + 0.535 nseg) cell-equivalents (x 1.014 at W = 22, x 1.022 at W = 24: three waves per SIMD), during
+// which a wave retires nseg rows of lb cells.  The nseg term stands for what short sequences pay per alignment
+// and per task (virtual row, pipeline fill, profile build).  Minimise cost per retired row over the variants
+// whose 64*W columns cover lb.
 int pc_nw_choose_variant(int lb) {
     if (lb <= 0) return -1;
     int best = -1; double best_cost = 0;
@@ -435,7 +437,8 @@ int pc_nw_choose_variant(int lb) {
         const int G = (lb + W - 1) / W;
         if (G > 64) continue;
         int nseg = 64 / G; if (nseg > 16) nseg = 16;
-        const double cost = (W + 4.4 + 0.47 * nseg) / nseg;
+        const double pen = W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
+        const double cost = (W + 1.02 + 0.535 * nseg) * pen / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
     return best;
