@@ -62,7 +62,14 @@ def cpu_baseline(packed, metric, min_seconds):
         per_row = max(dt / (hi - rows_done), 1e-9)
         rows_done = hi
         chunk = max(1, min(int((min_seconds - elapsed) / per_row * 1.1) + 1, 4 * chunk))
-    return {"value": pairs / elapsed, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+    # one thread as well (a short sample), so the per-core rate of the port is on record
+    one_rows = max(1, rows_done // max(threads, 1) // 4)
+    t0 = time.perf_counter()
+    _, a1, c1 = O.fill_rows(packed, metric, 0, one_rows, as_distance=True, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    pairs1 = sum(n - 1 - s for s in range(one_rows))
+    single = {"value": pairs1 / dt1, "cores": 1, "gcups": c1 / dt1 / 1e9, "seconds": dt1, "rows": one_rows}
+    return {"value": pairs / elapsed, "unit": "genome-pairs/s", "cores": threads, "kind": "port", "single_thread": single,
             "sample": f"oracle/pc_oracle.c (OpenMP, {threads} threads) on matrix rows [0,{rows_done}) of the same workload: "
                       f"{pairs} pairs, {aln} alignments, {cells} DP cells in {elapsed:.2f} s",
             "gcups": cells / elapsed / 1e9, "seconds": elapsed}

@@ -77,8 +77,9 @@ struct pc_ctx {
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // alignment launches of different classes overlap on these
-    hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kAux = 7;          // + the caller's stream = 8 concurrent alignment launches
+    hipStream_t aux[kAux] = {};             // alignment launches of different classes overlap on these
+    hipEvent_t aux_ev[kAux + 1] = {};
 };
 
 static int set_device(pc_ctx* c) { PC_HIP(hipSetDevice(c->device)); return PC_OK; }
@@ -95,8 +96,8 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < pc_ctx::kAux && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+    for (int i = 0; i <= pc_ctx::kAux && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_plan, 4096, hipHostMallocDefault);
     if (e != hipSuccess) { pc_set_error("pc_ctx_create: %s", hipGetErrorString(e)); pc_ctx_destroy(c); return PC_ERR_HIP; }
     *out = c;
@@ -114,8 +115,8 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
                       &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 3; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
-    for (int i = 0; i < 4; ++i) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
+    for (int i = 0; i < pc_ctx::kAux; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
+    for (int i = 0; i <= pc_ctx::kAux; ++i) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
     if (c->h_plan) (void)hipHostFree(c->h_plan);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -298,7 +299,7 @@ extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? 
 // Steps 5 of the plan: launch the alignment kernels for every class that has tasks.
 // Step 5 of the plan: launch the alignment kernels for every class that has tasks.  Classes are
 // independent (disjoint result slots), so their launches are spread over the caller's stream and
-// three auxiliary streams: the drain of one class overlaps the next one's start.
+// seven auxiliary streams: the drain of one class overlaps the next one's start.
 static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats, int ppos) {
     const int ncls = (int)c->cls_variant.size();
     std::vector<int> order;
@@ -313,8 +314,9 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
     size_t sbytes = 0;
     for (int i : order) if (ppos || c->cls_variant[i] < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(c->cls_max_lb[i]));
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
-    PC_HIP(hipEventRecord(c->aux_ev[3], st));
-    for (int k = 0; k < 3; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[3], 0));
+    constexpr int kAux = pc_ctx::kAux;
+    PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
+    for (int k = 0; k < kAux; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[kAux], 0));
     int slot = 0;
     for (int i : order) {
         const int nt = (int)(task_begin[i + 1] - task_begin[i]);
@@ -326,9 +328,9 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
                               variant < 0 ? c->b_scratch.cap : 0, c->cls_max_lb[i], ppos, ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
-        slot = (slot + 1) & 3;
+        slot = (slot + 1) % (kAux + 1);
     }
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < kAux; ++k) {
         PC_HIP(hipEventRecord(c->aux_ev[k], c->aux[k]));
         PC_HIP(hipStreamWaitEvent(st, c->aux_ev[k], 0));
     }
