@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -80,6 +81,7 @@ struct pc_ctx {
     static constexpr int kAux = 7;          // + the caller's stream = 8 concurrent alignment launches
     hipStream_t aux[kAux] = {};             // alignment launches of different classes overlap on these
     hipEvent_t aux_ev[kAux + 1] = {};
+    int n_streams = kAux + 1;               // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
 };
 
 static int set_device(pc_ctx* c) { PC_HIP(hipSetDevice(c->device)); return PC_OK; }
@@ -98,6 +100,7 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < pc_ctx::kAux && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
     for (int i = 0; i <= pc_ctx::kAux && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
+    if (const char* env = getenv("PC_ALIGN_STREAMS")) { int v = atoi(env); if (v >= 1 && v <= pc_ctx::kAux + 1) c->n_streams = v; }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_plan, 4096, hipHostMallocDefault);
     if (e != hipSuccess) { pc_set_error("pc_ctx_create: %s", hipGetErrorString(e)); pc_ctx_destroy(c); return PC_ERR_HIP; }
     *out = c;
@@ -328,7 +331,7 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
                               variant < 0 ? c->b_scratch.cap : 0, c->cls_max_lb[i], ppos, ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
-        slot = (slot + 1) % (kAux + 1);
+        slot = (slot + 1) % c->n_streams;
     }
     for (int k = 0; k < kAux; ++k) {
         PC_HIP(hipEventRecord(c->aux_ev[k], c->aux[k]));

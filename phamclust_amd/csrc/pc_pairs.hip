@@ -134,20 +134,33 @@ __global__ __launch_bounds__(512) void k_set_popc(PcDev d, PcShard sh, int as_di
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    // staging: thread (r0 = tid>>5, w = tid&31) moves word w of rows r0, r0+16, r0+32, r0+48 of both tiles.
+    // The next chunk's words are fetched into registers while the current chunk is being counted.
+    const int r0 = threadIdx.x >> 5, wl = threadIdx.x & 31;
+    const uint64_t* ps[4]; const uint64_t* pt[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = s0 + r0 + 16 * p, k = k0 + r0 + 16 * p;
+        ps[p] = s < d.N ? d.bitmap + (int64_t)s * d.Wstride : nullptr;
+        pt[p] = k < sh.nown ? d.bitmap + (int64_t)sh.owned[k] * d.Wstride : nullptr;
+    }
+    uint64_t vs[4], vt[4];
+    auto fetch = [&](int w0) {
+        const int w = w0 + wl;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            vs[p] = (ps[p] && w < d.Wb) ? ps[p][w] : 0ULL;
+            vt[p] = (pt[p] && w < d.Wb) ? pt[p][w] : 0ULL;
+        }
+    };
+    fetch(0);
     for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
         const int wn = min(PWCH, d.Wb - w0);
         if (w0) __syncthreads();
-        for (int r = threadIdx.x >> 5; r < PT; r += 16) {      // stage 64 + 64 rows, 32 words (256 B) per row per pass
-            const int s = s0 + r, k = k0 + r;
-            const int w = threadIdx.x & 31;
-            uint64_t vs = 0, vt = 0;
-            if (w < wn) {
-                if (s < d.N) vs = d.bitmap[(int64_t)s * d.Wstride + w0 + w];
-                if (k < sh.nown) vt = d.bitmap[(int64_t)sh.owned[k] * d.Wstride + w0 + w];
-            }
-            rs[r][w] = vs; rt[r][w] = vt;
-        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { rs[r0 + 16 * p][wl] = vs[p]; rt[r0 + 16 * p][wl] = vt[p]; }
         __syncthreads();
+        if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
         if (condensed) {
             for (int w = 0; w < wn; ++w) {
                 uint64_t a[2], b[4];
