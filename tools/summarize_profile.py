@@ -36,7 +36,7 @@ for r in rows:
         nw.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 for v in per.values():
     v["avg_ms"] = v["total_ms"] / v["calls"]
-# alignment launches of one fill overlap on 4 streams: group launches into fills by gaps > 1 ms between them
+# alignment launches of one fill overlap on several streams: group launches into fills by gaps > 1 ms between them
 nw.sort()
 spans, cur_s, cur_e = [], None, None
 for s, e in nw:
@@ -50,7 +50,7 @@ if cur_s is not None:
     spans.append((cur_e - cur_s) / 1e6)
 out = {"note": a.note, "fills": a.fills, "kernels": dict(sorted(per.items(), key=lambda kv: -kv[1]["total_ms"])),
        "k_nw_systolic": {"launches_per_fill": len(nw) / max(a.fills, 1), "sum_of_durations_ms_per_fill": sum(e - s for s, e in nw) / 1e6 / max(a.fills, 1),
-                         "span_ms_per_fill": spans, "comment": "launches of different column-gene classes overlap on 4 streams; span = first start to last end "
+                         "span_ms_per_fill": spans, "comment": "launches of different column-gene classes overlap on several streams; span = first start to last end "
                                                                "of one fill's launches = what bench.py times with HIP events (roofline.ms_kernels_per_fill)"}}
 
 
