@@ -229,6 +229,16 @@ __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// SH of column slot `want` (wave-uniform, runtime) picked with compile-time register indices only: a loop over c
+// with `if (c == want)` lets the compiler keep a scratch-memory copy of the whole array up to date in the hot loop.
+template <int W, int C>
+struct PcPick {
+    static __device__ __forceinline__ uint32_t get(const uint32_t (&SHu)[W], int want) {
+        if constexpr (C + 1 < W) { const uint32_t rest = PcPick<W, C + 1>::get(SHu, want); return want == C ? SHu[C] : rest; }
+        else return SHu[C];
+    }
+};
+
 template <int W>
 __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
@@ -399,9 +409,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
         const uint32_t SD0 = SHd + K + (ac == (int)(bc[0] & 0xffu) ? 1u : 0u);
         PcRow<W, 0>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, ac, K, o_E, o_SE);
         if ((a & PCF_LAST) && is_out) {
-            uint32_t st = SHu[0];
-#pragma unroll
-            for (int c = 1; c < W; ++c) if (c == c_out) st = SHu[c];
+            const uint32_t st = PcPick<W, 0>::get(SHu, c_out);
             res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
             out_r += nseg;
         }
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
 }
 
 // columns-per-lane of the compiled systolic variants
-static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24};
+static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 32, 48, 64};
 static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 
 int pc_nw_num_variants() { return g_num_variants; }
@@ -437,7 +445,9 @@ int pc_nw_choose_variant(int lb) {
         const int G = (lb + W - 1) / W;
         if (G > 64) continue;
         int nseg = 64 / G; if (nseg > 16) nseg = 16;
-        const double pen = W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
+        // W >= 32 exist for very long column genes (up to 4,096 residues): 2 or 1 waves per SIMD, so they are
+        // priced out wherever a narrower variant covers the gene
+        const double pen = W >= 64 ? 2.4 : W >= 48 ? 1.8 : W >= 32 ? 1.3 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
         const double cost = (W + 1.02 + 0.535 * nseg) * pen / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
@@ -476,7 +486,7 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
         switch (g_variant_w[variant]) {
 #define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
         PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
-        PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24)
+        PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24) PC_CASE(32) PC_CASE(48) PC_CASE(64)
 #undef PC_CASE
         default: pc_set_error("pc_launch_nw: no kernel for variant %d", variant); return PC_ERR_ARG;
         }
