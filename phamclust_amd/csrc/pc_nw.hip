@@ -445,9 +445,10 @@ int pc_nw_choose_variant(int lb) {
         const int G = (lb + W - 1) / W;
         if (G > 64) continue;
         int nseg = 64 / G; if (nseg > 16) nseg = 16;
-        // W >= 32 exist for very long column genes (up to 4,096 residues): 2 or 1 waves per SIMD, so they are
-        // priced out wherever a narrower variant covers the gene
-        const double pen = W >= 64 ? 2.4 : W >= 48 ? 1.8 : W >= 32 ? 1.3 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
+        // W >= 32 exist for very long column genes (up to 4,096 residues).  They run at 2 or 1 waves per SIMD yet
+        // measure 1.9-2.2 TCUPS at full lane use (profiles/r01_o_wide_variant_gcups.txt): one wave can keep its
+        // SIMD's VALU busy, so the penalty is small
+        const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
         const double cost = (W + 1.02 + 0.535 * nseg) * pen / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
