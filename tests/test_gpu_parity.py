@@ -279,3 +279,48 @@ def test_matrix_de_novo_drop_in(native_built, small_genomes):
     # pairwise call of the same callable agrees with the matrix cell
     s, t = small_genomes[3], small_genomes[17]
     assert METRICS["peq"](s, t, as_distance=True) == m.get_weight(s.name, t.name)
+
+
+def test_fill_distributed_single_rank(gpu_ctx, native_built):
+    """The product's multi-GPU entry point with a 1-rank group: shard -> (no gather) -> device assembly."""
+    import torch
+    import torch.distributed as dist
+    from phamclust_amd.distributed import fill_distributed
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(70, 400, seed=8)
+    gpu_ctx.upload(packed)
+    want = gpu_ctx.fill("peq")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        out, stats = fill_distributed(gpu_ctx, "peq", True)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want) and stats["n_pairs"] == packed.n_pairs
+    finally:
+        if created:
+            dist.destroy_process_group()
+        gpu_ctx.set_shard(0, 1)
+
+
+def test_bench_json_contract(native_built):
+    """bench.py prints ONE JSON line with the contract's keys (small workload, as a subprocess)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--genomes", "300", "--steps", "1", "--warmup", "1",
+                           "--cpu-seconds", "1", "--verify-pairs", "2000"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("synth(300,5000) -m peq") and d["data"] == "synthetic"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["verified"]["bit_exact"] is True and d["value"] > 0
