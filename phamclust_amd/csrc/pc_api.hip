@@ -405,7 +405,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 24, hipMemcpyDeviceToHost, st));
         PC_HIP(hipStreamSynchronize(st));
         const uint64_t A = h_tot[0];
-        if (A >= 0xffffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^32-1 per-call limit; shard the job", (unsigned long long)A); return PC_ERR_LIMIT; }
+        if (A >= 0x7fffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^31-1 per-call limit; shard the job (pc_set_shard)", (unsigned long long)A); return PC_ERR_LIMIT; }
         const uint32_t ntasks = c->h_plan[ncls];
         local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2]; local.n_tasks = ntasks;
         if ((rc = c->b_bucket_row.ensure(std::max<uint64_t>(A, 1) * 4)) || (rc = c->b_bucket_dest.ensure(std::max<uint64_t>(A, 1) * 4)) ||
