@@ -71,7 +71,7 @@ struct pc_ctx {
     PcShard shard{};
     // persistent device arrays
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
-    DevBuf b_cls_order, b_cls_idx, b_owned, b_lbase;
+    DevBuf b_cls_order, b_cls_idx, b_task_rows, b_owned, b_lbase;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_col_cnt, b_col_start, b_col_cur, b_cnt_q, b_start_q, b_ntask_q, b_task_off_q, b_scan_tmp;
     DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
@@ -112,7 +112,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
-                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_cls_order, &c->b_cls_idx, &c->b_owned, &c->b_lbase,
+                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_cls_order, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase,
                       &c->b_na, &c->b_off, &c->b_col_cnt, &c->b_col_start, &c->b_col_cur, &c->b_cnt_q, &c->b_start_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_bucket_row, &c->b_bucket_dest,
                       &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut};
@@ -243,10 +243,13 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     const int nvar = pc_nw_num_variants();
     const int ncls_all = nvar * 4 + 1;                 // last class: general kernel
     std::vector<int> gene_cls(G);
+    std::vector<int32_t> task_rows(std::max(G, 1), PC_TASK_ROWS);
     std::vector<int64_t> cls_count(ncls_all, 0);
     std::vector<int> cls_maxlb(ncls_all, 0);
     for (int k = 0; k < G; ++k) {
-        const int cls = pc_class_of(gene_len[k], pc_nw_choose_variant(gene_len[k]));
+        const int variant = pc_nw_choose_variant(gene_len[k]);
+        const int cls = pc_class_of(gene_len[k], variant);
+        task_rows[k] = pc_nw_task_rows(gene_len[k], variant);
         gene_cls[k] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], gene_len[k]);
     }
     c->cls_variant.clear(); c->cls_begin.clear(); c->cls_max_lb.clear();
@@ -270,7 +273,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
         (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
         (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_vec(c->b_codes, codes)) || (rc = upload_vec(c->b_nph, nph)) ||
-        (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_cls_order, cls_order)) ||
+        (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_cls_order, cls_order)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
         (rc = upload_vec(c->b_cls_idx, c->cls_begin)))
         return rc;
     PcDev& d = c->dev;
@@ -307,9 +310,15 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
     const int ncls = (int)c->cls_variant.size();
     std::vector<int> order;
     for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
+    // longest tasks first (a task's duration grows with its column gene's length): the tail of the fill is then made
+    // of short tasks.  PC_ALIGN_ORDER=size restores largest-class-first for A/B runs
+    static const bool by_size = getenv("PC_ALIGN_ORDER") && !strcmp(getenv("PC_ALIGN_ORDER"), "size");
     std::sort(order.begin(), order.end(), [&](int x, int y) {
-        const uint32_t nx = task_begin[x + 1] - task_begin[x], ny = task_begin[y + 1] - task_begin[y];
-        return nx != ny ? nx > ny : x < y;
+        if (by_size) {
+            const uint32_t nx = task_begin[x + 1] - task_begin[x], ny = task_begin[y + 1] - task_begin[y];
+            return nx != ny ? nx > ny : x < y;
+        }
+        return c->cls_max_lb[x] != c->cls_max_lb[y] ? c->cls_max_lb[x] > c->cls_max_lb[y] : x < y;
     });
     if (order.empty()) return PC_OK;
     // scratch of the general kernel: sized once for the longest column gene that will use it (never re-allocated
@@ -395,7 +404,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         // 2 scans
         const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
         if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-        if ((rc = pc_launch_task_count(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_cnt_q.as<uint32_t>(), c->b_ntask_q.as<uint32_t>(), G, st))) return rc;
+        if ((rc = pc_launch_task_count(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_task_rows.as<int32_t>(), c->b_cnt_q.as<uint32_t>(), c->b_ntask_q.as<uint32_t>(), G, st))) return rc;
         if ((rc = pc_scan_exclusive_u32(c->b_cnt_q.as<uint32_t>(), c->b_start_q.as<uint32_t>(), G + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
         if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), G + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
         // 3 read-back: task range per class + totals
@@ -412,7 +421,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
             (rc = c->b_res.ensure(std::max<uint64_t>(A, 1) * 8)) || (rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))))
             return rc;
         // 4 ENUM
-        if ((rc = pc_launch_task_fill(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_start_q.as<uint32_t>(),
+        if ((rc = pc_launch_task_fill(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_task_rows.as<int32_t>(), c->b_start_q.as<uint32_t>(),
                                       c->b_task_off_q.as<uint32_t>(), c->b_col_start.as<uint32_t>(), c->b_tasks.as<PcTask>(), G, st))) return rc;
         PC_HIP(hipMemsetAsync(c->b_col_cur.p, 0, (G + 1) * 4, st));
         a.off = c->b_off.as<uint32_t>(); a.col_start = c->b_col_start.as<uint32_t>(); a.col_cur = c->b_col_cur.as<uint32_t>();
@@ -521,8 +530,9 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
             while (cur_cls < cls[k]) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
             int64_t j = i;
             while (j < n && cls[order[j]] == cls[k] && b_gene[order[j]] == b_gene[k]) ++j;
-            for (int64_t r = i; r < j; r += PC_TASK_ROWS) {
-                PcTask t; t.gene = b_gene[k]; t.begin = (int32_t)r; t.end = (int32_t)std::min<int64_t>(j, r + PC_TASK_ROWS); t.pad = 0;
+            const int per = pc_nw_task_rows(c->h_gene_len[b_gene[k]], cls[k] == ncls_all - 1 ? -1 : cls[k] / 4);
+            for (int64_t r = i; r < j; r += per) {
+                PcTask t; t.gene = b_gene[k]; t.begin = (int32_t)r; t.end = (int32_t)std::min<int64_t>(j, r + per); t.pad = 0;
                 tasks.push_back(t);
             }
             cls_maxlb[cls[k]] = std::max(cls_maxlb[cls[k]], (int)c->h_gene_len[b_gene[k]]);

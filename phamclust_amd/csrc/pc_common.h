@@ -11,6 +11,7 @@
 // rows; rows are dealt to 4*nseg slots, so a wave receives ceil(R / (4 nseg)) * nseg of them: 208 is the
 // largest R for which that is <= 64 for every nseg in 1..16.
 #define PC_TASK_ROWS 208
+#define PC_TASK_BUDGET 32768          // cell slots per row stream of a task (pc_nw_task_rows)
 #define PC_MAX_W 64           // widest systolic variant: 64 lanes * 64 columns = 4096 columns
 
 // Device view of the uploaded genomes (all pointers are HBM).
@@ -77,8 +78,8 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
-int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st);
-int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const uint32_t* start_q, const uint32_t* task_off_q,
+int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st);
+int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, const uint32_t* start_q, const uint32_t* task_off_q,
                         uint32_t* col_start, PcTask* tasks, int G, hipStream_t st);
 int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st);
 int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st);
@@ -89,6 +90,7 @@ int pc_launch_unpack_res(const uint2* res, const int32_t* la_plus_lb, int32_t* n
 int pc_nw_num_variants();
 int pc_nw_variant_w(int v);                       // columns per lane of variant v
 int pc_nw_choose_variant(int lb);                 // -1: general fallback
+int pc_nw_task_rows(int lb, int variant);         // rows per workgroup task for that column gene
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, hipStream_t st);
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

@@ -455,6 +455,27 @@ int pc_nw_choose_variant(int lb) {
     return best;
 }
 
+// Rows (alignments) per workgroup task for a column gene of lb residues.  A task's 4*nseg row streams each walk
+// rows/(4*nseg) rows of ~lb residues, one residue per step, a step costing ~(W+1) cell slots: a fixed 208 rows makes
+// the tasks of long genes (one segment per wave) run a hundred times longer than those of short ones, and the
+// longest task bounds the fill from below once the work is split over ranks (or N is small).  So a stream is capped
+// at ~PC_TASK_BUDGET cell slots (never below one row per stream, never above PC_TASK_ROWS rows per task).
+static int task_budget() {
+    static int b = 0;
+    if (!b) { const char* e = getenv("PC_TASK_BUDGET"); b = e ? atoi(e) : 0; if (b <= 0) b = PC_TASK_BUDGET; }
+    return b;
+}
+int pc_nw_task_rows(int lb, int variant) {
+    if (variant < 0 || variant >= g_num_variants || lb <= 0) return 64;       // general kernel: one pass of 64 rows
+    const int W = g_variant_w[variant];
+    const int G = (lb + W - 1) / W;
+    int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
+    const int64_t steps = task_budget() / (W + 1);
+    int64_t per_stream = steps / (lb + 1); if (per_stream < 1) per_stream = 1;
+    const int64_t rows = per_stream * PC_WAVES * nseg;
+    return (int)(rows > PC_TASK_ROWS ? PC_TASK_ROWS : rows);
+}
+
 template <int W>
 static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                            const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {

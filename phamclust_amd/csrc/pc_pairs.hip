@@ -440,16 +440,17 @@ int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t
 // Wave-task building.  Genes are visited in class order (grouped by kernel variant).
 // ---------------------------------------------------------------------------------
 __global__ void k_task_count(const int32_t* __restrict__ cls_order, const uint32_t* __restrict__ col_cnt,
-                             uint32_t* __restrict__ cnt_q, uint32_t* __restrict__ ntask_q, int G) {
+                             const int32_t* __restrict__ task_rows, uint32_t* __restrict__ cnt_q, uint32_t* __restrict__ ntask_q, int G) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > G) return;
-    uint32_t n = q < G ? col_cnt[cls_order[q]] : 0u;
+    const int g = q < G ? cls_order[q] : 0;
+    const uint32_t n = q < G ? col_cnt[g] : 0u, per = q < G ? (uint32_t)task_rows[g] : 1u;
     cnt_q[q] = n;
-    ntask_q[q] = (n + PC_TASK_ROWS - 1) / PC_TASK_ROWS;
+    ntask_q[q] = (n + per - 1) / per;
 }
 
 __global__ void k_task_fill(const int32_t* __restrict__ cls_order, const uint32_t* __restrict__ col_cnt,
-                            const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ task_off_q,
+                            const int32_t* __restrict__ task_rows, const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ task_off_q,
                             uint32_t* __restrict__ col_start, PcTask* __restrict__ tasks, int G) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= G) return;
@@ -457,20 +458,21 @@ __global__ void k_task_fill(const int32_t* __restrict__ cls_order, const uint32_
     const uint32_t n = col_cnt[g], st = start_q[q];
     col_start[g] = st;
     uint32_t to = task_off_q[q];
-    for (uint32_t r = 0; r < n; r += PC_TASK_ROWS) {
-        PcTask t; t.gene = g; t.begin = (int32_t)(st + r); t.end = (int32_t)(st + min(n, r + PC_TASK_ROWS)); t.pad = 0;
+    const uint32_t per = (uint32_t)task_rows[g];
+    for (uint32_t r = 0; r < n; r += per) {
+        PcTask t; t.gene = g; t.begin = (int32_t)(st + r); t.end = (int32_t)(st + min(n, r + per)); t.pad = 0;
         tasks[to++] = t;
     }
 }
 
-int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st) {
-    hipLaunchKernelGGL(k_task_count, dim3((G + 1 + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, cnt_q, ntask_q, G);
+int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st) {
+    hipLaunchKernelGGL(k_task_count, dim3((G + 1 + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, task_rows, cnt_q, ntask_q, G);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
-int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const uint32_t* start_q, const uint32_t* task_off_q,
+int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, const uint32_t* start_q, const uint32_t* task_off_q,
                         uint32_t* col_start, PcTask* tasks, int G, hipStream_t st) {
     if (G <= 0) return PC_OK;
-    hipLaunchKernelGGL(k_task_fill, dim3((G + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, start_q, task_off_q, col_start, tasks, G);
+    hipLaunchKernelGGL(k_task_fill, dim3((G + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, task_rows, start_q, task_off_q, col_start, tasks, G);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
