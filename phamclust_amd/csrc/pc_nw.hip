@@ -141,9 +141,10 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 // ordinary recurrence produce the boundary H(-1,j) = -(11+j) with zero stats), so the
 // pipeline fills once per task, not once per alignment.  The stream is staged through LDS
 // 32 entries at a time (coalesced residue reads); the head lane of a segment only reads
-// one 16-bit entry per step.  The lane holding column lb-1 emits (n_ident, aln_len) when a
+// one 32-bit entry per step.  The lane holding column lb-1 emits (n_ident, aln_len) when a
 // row flagged LAST leaves it.  Substitution scores come from a per-task profile in LDS:
-// prof[r][k][c] = S(r, b_j)+11, one ds_read of W bytes per lane per row.
+// prof[k][r][c] = S(r, b_j)+12 (lane-major: a lane's 24 strips are contiguous, so the strip address is the lane's
+// table base plus the row offset that travels in the stream entry's high half), one ds_read of W bytes per lane per row.
 //
 // Scores are kept with an anti-diagonal bias: every stored H, E, F of cell (i,j) carries
 // + (i + j).  Because the extend cost is exactly 1 per step, both extend decrements vanish:
@@ -155,8 +156,10 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 // overwritten (so no register copies), and every VALU-written SGPR pair read >= 2
 // instructions later (gfx950 needs 2 wait states there; hipcc pads nothing inside asm).
 // ---------------------------------------------------------------------------------
-#define PCF_RESET 0x100
-#define PCF_LAST 0x200
+// Stream entry (u32): byte 0 residue code | byte 1 flags | high half = byte offset of the code's profile row
+// inside a lane's strip table (so the profile address is one SDWA add, and each flag one SDWA compare).
+#define PCF_LAST 0x100
+#define PCF_RESET 0x200
 #define PC_MAX_SEG 16
 #define PC_WIN 32                                   // stream entries staged per refill
 
@@ -190,7 +193,7 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
         : [D] "v"(D), [SD] "v"(SD), [Hol] "v"(Hol), [El] "v"(El), [SHl] "v"(SHl), [SEl] "v"(SEl), [ac] "v"(ac),  \
           [bcn] "v"(bcn), [pwn] "v"(pwn), [K] "v"(K))
 
-#define PC_CMP(SEL) "v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:DWORD src1_sel:" SEL "\n\t"
+#define PC_CMP(SEL) "v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:BYTE_0 src1_sel:" SEL "\n\t"
 #define PC_NEXT_D(SEL) "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t"
 #define PC_NEXT_SD "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
 
@@ -223,7 +226,7 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
 };
 
 #define PC_WAVES 4                                  // waves per workgroup, sharing one profile
-#define PC_WREG (4 * 64 + 2 * PC_MAX_SEG + PC_MAX_SEG * PC_WIN / 2)   // u32 of private LDS per wave
+#define PC_WREG (4 * 64 + 2 * PC_MAX_SEG + PC_MAX_SEG * PC_WIN)   // u32 of private LDS per wave
 
 __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read inside ONE wave (in-order LDS queue)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -238,6 +241,22 @@ struct PcPick {
         else return SHu[C];
     }
 };
+
+// Lanes whose entry is the virtual row -1 (mask m, an SGPR pair written by the step prologue's SDWA compare) forget
+// the previous row: Hou := Fu := -inf.
+template <int W, int C>
+struct PcReset {
+    static __device__ __forceinline__ void run(int (&Hou)[W], int (&Fu)[W], int vneg, unsigned long long m) {
+        asm volatile("v_cndmask_b32 %0, %0, %2, %3\n\tv_cndmask_b32 %1, %1, %2, %3" : "+v"(Hou[C]), "+v"(Fu[C]) : "v"(vneg), "s"(m));
+        if constexpr (C + 1 < W) PcReset<W, C + 1>::run(Hou, Fu, vneg, m);
+    }
+};
+
+typedef __attribute__((address_space(3))) const uint32_t pc_lds_u32;
+typedef uint32_t pc_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t pc_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const pc_u32x2 pc_lds_u32x2;
+typedef __attribute__((address_space(3))) const pc_u32x4 pc_lds_u32x4;
 
 template <int W>
 __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
@@ -257,8 +276,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     uint32_t* row_hi = row_lo + 64;
     uint32_t* seg_len = row_hi + 64;                                 // [16] stream length per segment
     uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] local row whose record holds the window start
-    uint16_t* ring = (uint16_t*)(seg_cur + PC_MAX_SEG);              // [16][PC_WIN] staged stream entries
-    uint32_t* prof = smem + 144 + PC_WAVES * PC_WREG;                // [24][G][ND], shared by the 4 waves
+    uint32_t* ring = seg_cur + PC_MAX_SEG;                           // [16][PC_WIN] staged stream entries
+    uint32_t* prof = smem + 144 + PC_WAVES * PC_WREG;                // [G][24][ND], shared by the 4 waves
     for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + 12);   // S + 12: see the bias note
 
     const PcTask tk = tasks[blockIdx.x];
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
                     const int c = q * 4 + e;
                     if (c < W) v |= (uint32_t)(uint8_t)tab[r][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
                 }
-                prof[(r * G + k) * ND + q] = v;
+                prof[(k * 24 + r) * ND + q] = v;
             }
         }
     }
@@ -333,8 +352,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
     const int half = lane >> 5, hl = lane & 31;
-    const uint32_t prof_lane = (uint32_t)(k * ND) * 4u;            // byte offset of my strip inside a profile row
-    const uint32_t prof_rowb = (uint32_t)(G * ND) * 4u;            // bytes per profile row
+    // LDS byte address of my strip table (24 rows of ND dwords)
+    const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + (uint32_t)(in_seg ? k : 0) * (24u * ND * 4u);
     const uint32_t ring_lane = (uint32_t)(in_seg ? seg : 0) * PC_WIN;
 
     // Stage PC_WIN stream entries of every segment starting at stream position `base` (two segments per pass).
@@ -352,75 +371,104 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
                     if (i < 0) entry = PCF_RESET;
                     else {
                         const uint8_t* ap = d.codes + (((unsigned long long)row_hi[r] << 32) | row_lo[r]);
-                        entry = (uint32_t)ap[i] | (i == (int)row_la[r] - 1 ? PCF_LAST : 0);
+                        const uint32_t code = ap[i];
+                        entry = code | (i == (int)row_la[r] - 1 ? PCF_LAST : 0) | ((min(code, 23u) * (ND * 4u)) << 16);
                     }
                     if (hl == PC_WIN - 1) seg_cur[sg] = (uint32_t)r;
                 }
-                ring[sg * PC_WIN + hl] = (uint16_t)entry;
+                ring[sg * PC_WIN + hl] = entry;
             }
         }
         pc_wave_lds_sync();
     };
-    auto load_prof = [&](int code, uint32_t (&dst)[ND]) {           // my strip of profile row min(code, 23)
-        const uint32_t off = (uint32_t)__mul24(min(code & 0xff, 23), (int)prof_rowb) + prof_lane;
-        const uint32_t* pr = (const uint32_t*)((const char*)prof + off);
+    auto load_prof = [&](uint32_t entry, uint32_t (&dst)[ND]) {     // my strip of the entry's profile row
+        uint32_t addr;                                              // one instruction: the entry's high half + my table
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(entry), "v"(prof_lane));
+        if constexpr (ND % 4 == 0) {
+            pc_lds_u32x4* pr = (pc_lds_u32x4*)(size_t)addr;
 #pragma unroll
-        for (int q = 0; q < ND; ++q) dst[q] = pr[q];
+            for (int q = 0; q < ND / 4; ++q) { const pc_u32x4 v = pr[q]; dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w; }
+        } else if constexpr (ND % 2 == 0) {
+            pc_lds_u32x2* pr = (pc_lds_u32x2*)(size_t)addr;
+#pragma unroll
+            for (int q = 0; q < ND / 2; ++q) { const pc_u32x2 v = pr[q]; dst[2 * q] = v.x; dst[2 * q + 1] = v.y; }
+        } else {
+            pc_lds_u32* pr = (pc_lds_u32*)(size_t)addr;
+#pragma unroll
+            for (int q = 0; q < ND; ++q) dst[q] = pr[q];
+        }
     };
 
     // Software pipeline: at step t the row code `a` and its profile strip `pw` are already in registers; the
     // code of step t+1 (head: ring entry, others: the left neighbour's current code) and its strip are fetched
     // while the cells of step t execute, and the head's ring entry of step t+2 is read one step ahead of that.
     refill(0);
-    int a = is_head ? (int)ring[ring_lane] : 0;
-    int e_nxt = in_seg ? (int)ring[ring_lane + 1] : 0;             // head's entry for step 1 (PC_WIN >= 2)
+    uint32_t a = is_head ? ring[ring_lane] : 0u;
+    uint32_t e_nxt = ring[ring_lane + 1];                          // head's entry for step 1 (PC_WIN >= 2)
+    uint32_t e_b = 0;                                              // entry t+3 (entries t+2, t+3 are fetched as a pair on even steps)
     uint32_t pw[ND];
     load_prof(a, pw);
+    const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out);
+    const int v_hb = -22, v_neg = PC_NEG; const uint32_t v_zero = 0;   // boundary values the head lanes take (VGPR operands)
 
-    // One row step.  `a`/`pw` are this step's row code and profile strip; `a_nxt`/`pw_nxt` receive the next step's.
-    auto step = [&](int t, int a, const uint32_t (&pw)[ND], int& a_nxt, uint32_t (&pw_nxt)[ND]) {
-        if (((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
-        asm volatile("s_nop 1" ::: "memory");        // VALU (asm, previous step) -> DPP read: 2 wait states
-        // the DPP shift must run with every lane active (a masked-off source lane reads as 0), so it is
-        // computed unconditionally and selected afterwards -- never inside the branch of a ?:
-        const int a_left = __builtin_amdgcn_mov_dpp(a, 0x138, 0xf, 0xf, true);
-        a_nxt = is_head ? e_nxt : a_left;
+    // One row step.  `a`/`pw` are this step's stream entry and profile strip; `a_nxt`/`pw_nxt` receive the next step's.
+    auto step = [&](int t, const bool even, uint32_t a, const uint32_t (&pw)[ND], uint32_t& a_nxt, uint32_t (&pw_nxt)[ND]) {
+        if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
+        // Step prologue, 10 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
+        // k-1's value (DPP wave_shr:1 on src0, executed with every lane active), head lanes (vcc) take src1 = their
+        // boundary value instead: the next entry from the ring, Ho^(i,-1) = -22, E = -inf, stats 0.  The flag
+        // tests and the first cell's diagonal term use SDWA byte selects on the raw entry.  K.BYTE_2 == 1.
+        int Hol, El, D0; uint32_t SHl, SEl, SD0;
+        unsigned long long rstm, lastm, c2;
+        const int Hod = p_Hol; const uint32_t SHd = p_SHl;
+        asm volatile(
+            "s_nop 1\n\t"                                                   // VALU (previous step's cells) -> DPP read: 2 wait states
+            "s_mov_b64 vcc, %[hm]\n\t"
+            "v_cmp_eq_u32_sdwa %[c2], %[a], %[bc0] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+            "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_cndmask_b32_dpp %[Hol], %[Hw], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_cndmask_b32_dpp %[El], %[oE], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_cndmask_b32_dpp %[SHl], %[SHw], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_mov_b32_dpp %[SEl], %[oSE] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // head: E opens, SE := SHl
+            "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+            "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+            "v_add_u32_sdwa %[D0], %[pw0], %[Hod] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+            "v_addc_co_u32 %[SD0], %[c2], %[K], %[SHd], %[c2]\n\t"
+            : [an] "=&v"(a_nxt), [Hol] "=&v"(Hol), [El] "=&v"(El), [SHl] "=&v"(SHl), [SEl] "=&v"(SEl), [D0] "=&v"(D0),
+              [SD0] "=&v"(SD0), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
+            : [hm] "s"(headm), [a] "v"(a), [en] "v"(e_nxt), [Hw] "v"(Hou[W - 1]), [hb] "v"(v_hb), [oE] "v"(o_E), [neg] "v"(v_neg),
+              [SHw] "v"(SHu[W - 1]), [zero] "v"(v_zero), [oSE] "v"(o_SE), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
+              [Hod] "v"(Hod), [SHd] "v"(SHd)
+            : "vcc");
         load_prof(a_nxt, pw_nxt);
-        e_nxt = in_seg ? (int)ring[ring_lane + ((t + 2) & (PC_WIN - 1))] : 0;
-        int Hol = __builtin_amdgcn_mov_dpp(Hou[W - 1], 0x138, 0xf, 0xf, true);
-        int El = __builtin_amdgcn_mov_dpp(o_E, 0x138, 0xf, 0xf, true);
-        uint32_t SHl = (uint32_t)__builtin_amdgcn_mov_dpp((int)SHu[W - 1], 0x138, 0xf, 0xf, true);
-        uint32_t SEl = (uint32_t)__builtin_amdgcn_mov_dpp((int)o_SE, 0x138, 0xf, 0xf, true);
-        const bool rst = (a & PCF_RESET) != 0;
-        {   // head lanes: left boundary Ho^(i,-1) = -22, or Ho^(-1,-1) = -12 on the virtual row
-            const int hb = rst ? -12 : -22;
-            Hol = is_head ? hb : Hol; El = is_head ? PC_NEG : El;
-            SHl = is_head ? 0u : SHl;                 // SEl needs no fix-up: with El = -inf the head's E always opens
+        if (even) {                                                       // the head's entries for steps t+2 and t+3
+            const uint2 e2 = *(const uint2*)&ring[ring_lane + ((t + 2) & (PC_WIN - 1))];
+            e_nxt = e2.x; e_b = e2.y;
+        } else e_nxt = e_b;
+        if (rstm != 0) {                                                  // some lane starts an alignment this step (virtual row -1)
+            const unsigned long long hr = rstm & headm;
+            PcReset<W, 0>::run(Hou, Fu, v_neg, rstm);
+            asm volatile("v_cndmask_b32 %0, %0, %2, %3\n\tv_cndmask_b32 %1, %1, -12, %4"      // D := -inf; head: Ho^(-1,-1) = -12
+                         : "+v"(D0), "+v"(Hol) : "v"(v_neg), "s"(rstm), "s"(hr));
         }
-        int Hod = p_Hol; uint32_t SHd = p_SHl;
         p_Hol = Hol; p_SHl = SHl;
-        if (__builtin_amdgcn_ballot_w64(rst) != 0) {                     // some lane starts an alignment this step
-#pragma unroll
-            for (int c = 0; c < W; ++c) { Hou[c] = rst ? PC_NEG : Hou[c]; Fu[c] = rst ? PC_NEG : Fu[c]; }
-            Hod = rst ? PC_NEG : Hod;
-        }
-        const int ac = a & 0xff;
-        const int D0 = Hod + (int)(pw[0] & 0xffu);
-        const uint32_t SD0 = SHd + K + (ac == (int)(bc[0] & 0xffu) ? 1u : 0u);
-        PcRow<W, 0>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, ac, K, o_E, o_SE);
-        if ((a & PCF_LAST) && is_out) {
-            const uint32_t st = PcPick<W, 0>::get(SHu, c_out);
-            res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
-            out_r += nseg;
+        PcRow<W, 0>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, (int)a, K, o_E, o_SE);
+        if ((lastm & outm) != 0) {                                        // a row's last cell left the lane holding column lb-1
+            asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
+            if ((a & PCF_LAST) && is_out) {
+                const uint32_t st = PcPick<W, 0>::get(SHu, c_out);
+                res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
+                out_r += nseg;
+            }
         }
     };
     // two steps per iteration with the (code, strip) register sets swapping roles: no copies.  An odd T runs one
     // extra step past the end of every stream (idle entries: no flags, no output).
-    int a2 = 0; uint32_t pw2[ND];
+    uint32_t a2 = 0; uint32_t pw2[ND];
 #pragma unroll 1
     for (int t = 0; t < T; t += 2) {
-        step(t, a, pw, a2, pw2);
-        step(t + 1, a2, pw2, a, pw);
+        step(t, true, a, pw, a2, pw2);
+        step(t + 1, false, a2, pw2, a, pw);
     }
 }
 
@@ -431,12 +479,13 @@ static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 int pc_nw_num_variants() { return g_num_variants; }
 int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
 
-// Variant for a column gene of lb residues.  Least-squares fit to measured kernel-only GCUPS of every variant
-// over L = 60..1200 on MI355X (profiles/r01_l_variant_gcups.txt, mean error 2.3 %): time per row step
-// ~ (W + 1.02 + 0.535 nseg) cell-equivalents (x 1.014 at W = 22, x 1.022 at W = 24: three waves per SIMD), during
-// which a wave retires nseg rows of lb cells.  The nseg term stands for what short sequences pay per alignment
-// and per task (virtual row, pipeline fill, profile build).  Minimise cost per retired row over the variants
-// whose 64*W columns cover lb.
+// Variant for a column gene of lb residues.  Time per row step ~ (W + c0 + c1 nseg) cell-equivalents (x 1.014 at
+// W = 22, x 1.022 at W = 24: three waves per SIMD), during which a wave retires nseg rows of lb cells; c1 = 0.535
+// from a least-squares fit to measured kernel-only GCUPS of every variant over L = 60..1200
+// (profiles/r01_l_variant_gcups.txt), c0 = 0.3 after the step prologue shrank to ~12 instructions (end-to-end
+// sweep: the fill time is flat within 1 % over c0 = 0.3..1.0).  The nseg term stands for what short sequences pay
+// per alignment and per task (virtual row, pipeline fill, profile build).  Minimise cost per retired row over the
+// variants whose 64*W columns cover lb.  PC_CHOOSE_C0 / PC_CHOOSE_C1 override the constants for tuning runs.
 int pc_nw_choose_variant(int lb) {
     if (lb <= 0) return -1;
     int best = -1; double best_cost = 0;
@@ -449,7 +498,9 @@ int pc_nw_choose_variant(int lb) {
         // measure 1.9-2.2 TCUPS at full lane use (profiles/r01_o_wide_variant_gcups.txt): one wave can keep its
         // SIMD's VALU busy, so the penalty is small
         const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
-        const double cost = (W + 1.02 + 0.535 * nseg) * pen / nseg;
+        static const double c0 = getenv("PC_CHOOSE_C0") ? atof(getenv("PC_CHOOSE_C0")) : 0.3;
+        static const double c1 = getenv("PC_CHOOSE_C1") ? atof(getenv("PC_CHOOSE_C1")) : 0.535;
+        const double cost = (W + c0 + c1 * nseg) * pen / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
     return best;
