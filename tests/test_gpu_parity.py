@@ -281,6 +281,60 @@ def test_matrix_de_novo_drop_in(native_built, small_genomes):
     assert METRICS["peq"](s, t, as_distance=True) == m.get_weight(s.name, t.name)
 
 
+@pytest.mark.parametrize("metric", SET_METRICS)
+def test_full_size_set_metrics_vs_oracle(gpu_ctx, native_built, metric):
+    """BASELINE configs[1] at full size (synth(2000,5000): 1,999,000 pairs): every value against the oracle."""
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(2000, 5000)
+    got = gpu_ctx.upload(packed).fill(metric, as_distance=True)
+    want = O.fill(packed, metric, as_distance=True)
+    assert got.shape == (1999000,) and np.array_equal(got, want)
+
+
+def test_full_size_peq_properties(gpu_ctx, native_built):
+    """The headline configuration at full size (synth(5000,5000) -m peq, 12,497,500 pairs, 33.5 M alignments), through
+    properties that need no full CPU run: the fill is deterministic (bucket order comes from atomics); an 8-way
+    shard assembles to the unsharded matrix; peq == round(af * aai, 6) over three independent fills
+    (metrics.py:247-253); a value is zero exactly where no pham is shared; 20,000 random pairs equal the oracle."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(5000, 5000)
+    gpu_ctx.upload(packed)
+    n = packed.n_genomes
+    peq = gpu_ctx.fill("peq", as_distance=False)
+    assert peq.shape == (n * (n - 1) // 2,) and peq.min() >= 0.0 and peq.max() <= 1.0
+    assert np.array_equal(gpu_ctx.fill("peq", as_distance=False), peq)
+    af, aai, jc = (gpu_ctx.fill(m, as_distance=False) for m in ("af", "aai", "jc"))
+    product = af * aai                                   # both factors are the rounded similarities (metrics.py:247-252)
+    py_round = lambda arr: np.array([round(v, 6) for v in arr.tolist()])      # CPython's round: the reference's semantics
+    assert np.array_equal(peq, py_round(product))
+    assert not peq[jc == 0.0].any() and not aai[jc == 0.0].any() and not af[jc == 0.0].any()
+    dist = gpu_ctx.fill("peq", as_distance=True)
+    assert np.array_equal(dist, py_round(1.0 - product))                      # metrics.py:250-253
+    # 8-way shard, gathered by hand on the one GPU
+    stream = torch.cuda.current_stream().cuda_stream
+    parts = []
+    for rank in range(8):
+        gpu_ctx.set_shard(rank, 8)
+        buf = torch.empty(gpu_ctx.shard_stride(), dtype=torch.float64, device="cuda:0")
+        gpu_ctx.fill_shard_dev("peq", True, buf.data_ptr(), stream)
+        parts.append(buf)
+    out = torch.empty(packed.n_pairs, dtype=torch.float64, device="cuda:0")
+    gpu_ctx.assemble_dev(torch.cat(parts).data_ptr(), 8, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    gpu_ctx.set_shard(0, 1)
+    assert np.array_equal(out.cpu().numpy(), dist)
+    rng = np.random.default_rng(5)
+    a, b = rng.integers(0, n, 20000), rng.integers(0, n, 20000)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    keep = lo < hi
+    lo, hi = lo[keep], hi[keep]
+    idx = lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)
+    assert np.array_equal(dist[idx], O.pairs(packed, "peq", lo, hi, as_distance=True))
+
+
 def test_fill_distributed_single_rank(gpu_ctx, native_built):
     """The product's multi-GPU entry point with a 1-rank group: shard -> (no gather) -> device assembly."""
     import torch
