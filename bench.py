@@ -91,12 +91,20 @@ def main():
     from phamclust_amd.distributed import fill_distributed
     from phamclust_amd.synth import synth_packed
 
+    # PC_BENCH_BACKEND=gloo rehearses the N>1 flow on a box with fewer GPUs than ranks (ranks share devices, the
+    # gather is staged through host memory); the measured configuration is always nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("PC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if local_rank == 0:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         build.build_all()                 # no-op when the in-tree libraries are current; one rank only
     if world > 1:
         dist.barrier()
@@ -164,7 +172,8 @@ def main():
         "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill",
                    "n_genomes": a.genomes, "n_phams": packed.n_phams, "metric_selector": a.metric, "genome_pairs": n_pairs,
                    "n_genes": packed.n_genes, "n_residues": int(packed.residues.size),
-                   "parallelism": f"static pair shard over {world} GPU(s)" + (" + 1 RCCL gather + device assembly" if world > 1 else "")},
+                   "parallelism": f"static pair shard over {world} GPU(s)" + (" + 1 RCCL gather + device assembly" if world > 1 else "")
+                                  + ("" if backend == "nccl" or world == 1 else f" [REHEARSAL: backend {backend}, ranks share GPUs]")},
     }
     if a.metric in ("aai", "peq"):
         # this rank-set's K4 launches of one fill; multi-GPU: work of all ranks / slowest rank's time

@@ -79,6 +79,12 @@ def fill_distributed(ctx, metric, as_distance=True, group=None):
     stats = ctx.fill_shard_dev(metric, as_distance, shard.data_ptr(), stream)
     if world == 1:
         gathered = shard
+    elif dist.get_backend(group) == "gloo":
+        # rehearsal transport (several ranks sharing one GPU, or no RCCL): same shard / gather / assembly, staged
+        # through host memory because gloo gathers CPU tensors only
+        host = torch.empty(world * max(stride, 1), dtype=torch.float64) if rank == 0 else None
+        dist.gather(shard.cpu(), list(host.chunk(world)) if rank == 0 else None, dst=0, group=group)
+        gathered = host.to(device) if rank == 0 else None
     else:
         gathered = torch.empty(world * max(stride, 1), dtype=torch.float64, device=device) if rank == 0 else None
         dist.gather(shard, list(gathered.chunk(world)) if rank == 0 else None, dst=0, group=group)

@@ -378,3 +378,30 @@ def test_bench_json_contract(native_built):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["verified"]["bit_exact"] is True and d["value"] > 0
+
+
+def test_bench_two_ranks_rehearsal(native_built):
+    """bench.py under the driver's launcher with 2 ranks.  This box has one GPU, so the ranks share it and the
+    gather goes through gloo (PC_BENCH_BACKEND=gloo): everything but the RCCL transport itself is the N>1 path --
+    rendezvous, build behind a barrier, shard fills, gather, device assembly, max-over-ranks timing, one JSON line
+    whose sampled pairs equal the oracle."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PC_BENCH_BACKEND="gloo")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--genomes", "301", "--steps", "2",
+                           "--warmup", "1", "--verify-pairs", "3000"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["genome_pairs"] == 301 * 300 // 2 and "REHEARSAL" in d["config"]["parallelism"]
+    assert d["verified"]["bit_exact"] is True and d["roofline"]["n_alignments"] > 0
