@@ -143,7 +143,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         agg = torch.tensor([[s["n_alignments"], s["n_cells"], s["n_residue_bytes"], s["n_tasks"], s["ms_align"] * 1e3,
-                             s["ms_total"] * 1e3] for s in stats], dtype=torch.float64, device="cuda")
+                             s["ms_total"] * 1e3, s["n_distinct_alignments"], s["n_distinct_cells"]] for s in stats],
+                           dtype=torch.float64, device="cuda")
         agg_sum = agg.clone(); dist.all_reduce(agg_sum, op=dist.ReduceOp.SUM)
         agg_max = agg.clone(); dist.all_reduce(agg_max, op=dist.ReduceOp.MAX)
         agg_min = agg.clone(); dist.all_reduce(agg_min, op=dist.ReduceOp.MIN)
@@ -156,11 +157,13 @@ def main():
     value = n_pairs * a.steps / elapsed
     if world == 1:
         n_aln = stats[-1]["n_alignments"]; n_cells = stats[-1]["n_cells"]; n_rbytes = stats[-1]["n_residue_bytes"]
+        n_daln = stats[-1]["n_distinct_alignments"]; n_dcells = stats[-1]["n_distinct_cells"]
         ms_align = sum(s["ms_align"] for s in stats) / len(stats)
         ms_dev = sum(s["ms_total"] for s in stats) / len(stats)
         align_span = None
     else:
         n_aln = int(agg_sum[-1, 0]); n_cells = int(agg_sum[-1, 1]); n_rbytes = int(agg_sum[-1, 2])
+        n_daln = int(agg_sum[-1, 6]); n_dcells = int(agg_sum[-1, 7])
         ms_align = float(agg_max[:, 4].mean()) / 1e3          # slowest rank's alignment time per step
         ms_dev = float(agg_max[:, 5].mean()) / 1e3
         align_span = [float(agg_min[:, 4].mean()) / 1e3, float(agg_max[:, 4].mean()) / 1e3]
@@ -185,7 +188,10 @@ def main():
             "traffic": None,
             "kernel": "k_nw_systolic<W> (all variant launches of one fill, per GPU)",
             "algorithmic_bytes_per_fill": algo_bytes, "ms_kernels_per_fill": ms_align,
-            "n_alignments": n_aln, "dp_cells": n_cells, "gcups_per_gpu": n_cells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0,
+            "n_alignments": n_aln, "dp_cells": n_cells,
+            # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
+            "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells,
+            "gcups_per_gpu": n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0,
             "note": "integer-VALU bound recurrence (no MFMA, little HBM traffic): GCUPS is the meaningful rate; "
                     "HBM fraction reported because the north star asks for it",
         }

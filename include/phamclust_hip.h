@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PC_VERSION 100   /* 0.1.0 */
+#define PC_VERSION 110   /* 0.1.1: pc_stats gained n_distinct_alignments / n_distinct_cells */
 
 typedef enum {
     PC_OK = 0,
@@ -70,7 +70,7 @@ typedef struct {
  * stream the kernels ran on. */
 typedef struct {
     int64_t n_pairs;            /* genome pairs produced by this call (this rank's shard)   */
-    int64_t n_alignments;       /* ordered sequence pairs aligned (aai/peq), else 0         */
+    int64_t n_alignments;       /* alignments the reference would run (aai/peq), else 0     */
     int64_t n_cells;            /* sum of la*lb over those alignments                       */
     int64_t n_tasks;            /* wave tasks launched by the alignment kernels             */
     int64_t n_residue_bytes;    /* sum of (la+lb) over alignments: algorithmic input bytes  */
@@ -80,6 +80,8 @@ typedef struct {
     float ms_plan;              /* pair walk: counts, scans, bucketing, task build          */
     float ms_align;             /* alignment kernels only (the dominant kernels)            */
     float ms_reduce;            /* best-match select + fp64 epilogue (or the set-metric kernel) */
+    int64_t n_distinct_alignments; /* distinct (row sequence, column sequence) pairs: what the kernels computed */
+    int64_t n_distinct_cells;   /* sum of la*lb over the distinct alignments                */
 } pc_stats;
 
 int pc_version(void);
@@ -112,7 +114,8 @@ int64_t pc_shard_stride(const pc_ctx* ctx);
 int pc_fill(pc_ctx* ctx, int metric, int as_distance, double* out_condensed, pc_stats* stats);
 
 /* Same, result left in HBM: out_dev is a device pointer to f64[N(N-1)/2]; `stream` is a
- * hipStream_t (NULL = the context's own stream).  Asynchronous w.r.t. the host except for
+ * hipStream_t; NULL is the legacy default stream, as everywhere in HIP (PyTorch's default stream has
+ * handle 0: work the caller queued there is ordered with these launches).  Asynchronous w.r.t. the host except for
  * one small plan read-back under aai/peq. */
 int pc_fill_dev(pc_ctx* ctx, int metric, int as_distance, void* out_dev, void* stream, pc_stats* stats);
 

@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-HIP_SOURCES = ["pc_api.hip", "pc_pairs.hip", "pc_nw.hip"]
+HIP_SOURCES = ["pc_api.hip", "pc_pairs.hip", "pc_plan.hip", "pc_nw.hip"]
 HIP_LIB = os.path.join(CSRC, "libphamclust_hip.so")
 SYNTH_LIB = os.path.join(CSRC, "libpc_synth.so")
 PACK_LIB = os.path.join(CSRC, "libpc_pack.so")

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string_view>
+#include <unordered_map>
 #include <vector>
 
 #include "pc_common.h"
@@ -71,9 +73,9 @@ struct pc_ctx {
     PcShard shard{};
     // persistent device arrays
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
-    DevBuf b_cls_order, b_cls_idx, b_task_rows, b_owned, b_lbase;
+    DevBuf b_gene_q, b_q_gene, b_cls_idx, b_task_rows, b_owned, b_lbase;
     // work buffers (grow-only)
-    DevBuf b_na, b_off, b_col_cnt, b_col_start, b_col_cur, b_cnt_q, b_start_q, b_ntask_q, b_task_off_q, b_scan_tmp;
+    DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
     DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
@@ -112,8 +114,9 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
-                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_cls_order, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase,
-                      &c->b_na, &c->b_off, &c->b_col_cnt, &c->b_col_start, &c->b_col_cur, &c->b_cnt_q, &c->b_start_q,
+                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase,
+                      &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
+                      &c->b_start_q, &c->b_end_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_bucket_row, &c->b_bucket_dest,
                       &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut};
     for (DevBuf* b : bufs) b->release();
@@ -238,19 +241,31 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
         for (int i = 0; i < gene_len[k]; ++i) dst[i] = lut[src[i]];
     }
-    // class order: genes grouped by the kernel variant that will align against them as columns, and by
-    // lanes-per-segment bucket (the profile's LDS footprint scales with it, and LDS sets occupancy)
+    // distinct sequences (by encoded residues: what the kernels compare).  Alignments are planned per distinct
+    // (row sequence, column sequence) pair, so every sequence gets a rank q; ranks follow launch-class order: column
+    // sequences grouped by the kernel variant that aligns against them and by lanes-per-segment bucket (the
+    // profile's LDS footprint scales with it, and LDS sets occupancy)
+    std::vector<int32_t> uid(G), u_gene;
+    {
+        std::unordered_map<std::string_view, int32_t> seen;
+        seen.reserve((size_t)G * 2 + 16);
+        for (int k = 0; k < G; ++k) {
+            const std::string_view sv((const char*)&codes[(size_t)gene_off[k]], (size_t)gene_len[k]);
+            auto it = seen.emplace(sv, (int32_t)u_gene.size());
+            if (it.second) u_gene.push_back(k);
+            uid[k] = it.first->second;
+        }
+    }
+    const int U = (int)u_gene.size();
     const int nvar = pc_nw_num_variants();
     const int ncls_all = nvar * 4 + 1;                 // last class: general kernel
-    std::vector<int> gene_cls(G);
-    std::vector<int32_t> task_rows(std::max(G, 1), PC_TASK_ROWS);
+    std::vector<int> u_cls(U);
     std::vector<int64_t> cls_count(ncls_all, 0);
     std::vector<int> cls_maxlb(ncls_all, 0);
-    for (int k = 0; k < G; ++k) {
-        const int variant = pc_nw_choose_variant(gene_len[k]);
-        const int cls = pc_class_of(gene_len[k], variant);
-        task_rows[k] = pc_nw_task_rows(gene_len[k], variant);
-        gene_cls[k] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], gene_len[k]);
+    for (int u = 0; u < U; ++u) {
+        const int len = gene_len[u_gene[u]];
+        const int cls = pc_class_of(len, pc_nw_choose_variant(len));
+        u_cls[u] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], len);
     }
     c->cls_variant.clear(); c->cls_begin.clear(); c->cls_max_lb.clear();
     std::vector<int64_t> cls_pos(ncls_all, 0);
@@ -263,9 +278,18 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         }
         c->cls_begin.push_back((int32_t)run);
     }
-    std::vector<int32_t> cls_order(std::max(G, 1));
-    for (int k = 0; k < G; ++k) cls_order[(size_t)cls_pos[gene_cls[k]]++] = k;
-    if ((c->cls_begin.size() + 8) * sizeof(uint32_t) + 3 * sizeof(uint64_t) > 4096) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }
+    std::vector<int32_t> q_gene(std::max(U, 1), 0), task_rows(std::max(U, 1), PC_TASK_ROWS);
+    std::vector<uint32_t> q_of_u(std::max(U, 1), 0), gene_q(std::max(G, 1), 0);
+    for (int u = 0; u < U; ++u) {
+        const int q = (int)cls_pos[u_cls[u]]++;
+        const int len = gene_len[u_gene[u]];
+        q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];
+        task_rows[q] = pc_nw_task_rows(len, u_cls[u] == ncls_all - 1 ? -1 : u_cls[u] / 4);
+    }
+    for (int k = 0; k < G; ++k) gene_q[k] = q_of_u[uid[k]];
+    int ubits = 1;
+    while ((1LL << ubits) < U) ++ubits;
+    if (c->cls_begin.size() > 900) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // h_plan: 1000 u32, then the totals
 
     // ---- device copies ---------------------------------------------------------------
     std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
@@ -273,11 +297,12 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
         (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
         (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_vec(c->b_codes, codes)) || (rc = upload_vec(c->b_nph, nph)) ||
-        (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_cls_order, cls_order)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
+        (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
         (rc = upload_vec(c->b_cls_idx, c->cls_begin)))
         return rc;
     PcDev& d = c->dev;
     d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)ent_cnt.size();
+    d.U = U; d.ubits = ubits; d.gene_q = c->b_gene_q.as<uint32_t>(); d.q_gene = c->b_q_gene.as<int32_t>();
     d.bitmap = c->b_bitmap.as<uint64_t>(); d.rankpre = c->b_rankpre.as<uint32_t>();
     d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
     d.gene_len = c->b_gene_len.as<int32_t>(); d.gene_off = c->b_gene_off.as<int64_t>(); d.codes = c->b_codes.as<uint8_t>();
@@ -336,7 +361,7 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
         // launches that use the one scratch slab stay in order on the caller's stream
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, c->b_tasks.as<PcTask>() + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
-                              c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
+                              nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
                               variant < 0 ? c->b_scratch.cap : 0, c->cls_max_lb[i], ppos, ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
@@ -356,7 +381,8 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     if (ppos) metric = PC_AAI;
     if (!out) { pc_set_error("fill: out is NULL"); return PC_ERR_ARG; }
     int rc = set_device(c); if (rc != PC_OK) return rc;
-    if (!st) st = c->stream;
+    // st == NULL is HIP's legacy default stream, used as such: a caller whose producers / consumers run on it (PyTorch's
+    // default stream has handle 0) is ordered with these launches; the library's own streams are non-blocking
     const PcDev& d = c->dev;
     const int64_t Lp = c->shard_pairs;
     pc_stats local; memset(&local, 0, sizeof(local));
@@ -385,55 +411,74 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         if (d.G > 0 && c->min_gene_len == 0) {
             pc_set_error("fill: an empty translation cannot be aligned (aai/peq); the reference fails on it too"); return PC_ERR_DATA;
         }
-        const int G = d.G;
+        const int U = d.U;
         const int ncls = (int)c->cls_variant.size();
-        const int64_t scan_n = std::max<int64_t>(Lp + 1, G + 1);
-        if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_col_cnt.ensure((G + 1) * 4)) ||
-            (rc = c->b_col_start.ensure((G + 1) * 4)) || (rc = c->b_col_cur.ensure((G + 1) * 4)) || (rc = c->b_cnt_q.ensure((G + 1) * 4)) ||
-            (rc = c->b_start_q.ensure((G + 1) * 4)) || (rc = c->b_ntask_q.ensure((G + 1) * 4)) || (rc = c->b_task_off_q.ensure((G + 1) * 4)) ||
-            (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(scan_n) * 4)) || (rc = c->b_totals.ensure(64)) || (rc = c->b_plan.ensure(4096)))
+        const int64_t tmp_fixed = std::max<int64_t>(Lp + 1, U + 1);
+        if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_start_q.ensure((U + 1) * 4)) ||
+            (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) || (rc = c->b_task_off_q.ensure((U + 1) * 4)) ||
+            (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(tmp_fixed) * 4)) || (rc = c->b_totals.ensure(64)) || (rc = c->b_plan.ensure(4096)))
             return rc;
-        // 1 COUNT
+        // 1 COUNT: alignments per pair (the reference's loop nest, metrics.py:204-224), totals
         PC_HIP(hipMemsetAsync(c->b_na.p, 0, (Lp + 1) * 4, st));
-        PC_HIP(hipMemsetAsync(c->b_col_cnt.p, 0, (G + 1) * 4, st));
         PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, st));
         PcWalkArgs a; memset(&a, 0, sizeof(a));
-        a.na = c->b_na.as<uint32_t>(); a.col_cnt = c->b_col_cnt.as<uint32_t>(); a.totals = c->b_totals.as<unsigned long long>();
+        a.na = c->b_na.as<uint32_t>(); a.totals = c->b_totals.as<unsigned long long>();
         a.as_distance = as_distance; a.condensed = condensed;
         if ((rc = pc_launch_walk(PCW_COUNT, d, c->shard, a, st))) return rc;
-        // 2 scans
-        const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
-        if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-        if ((rc = pc_launch_task_count(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_task_rows.as<int32_t>(), c->b_cnt_q.as<uint32_t>(), c->b_ntask_q.as<uint32_t>(), G, st))) return rc;
-        if ((rc = pc_scan_exclusive_u32(c->b_cnt_q.as<uint32_t>(), c->b_start_q.as<uint32_t>(), G + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-        if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), G + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-        // 3 read-back: task range per class + totals
-        if ((rc = pc_launch_gather_u32(c->b_task_off_q.as<uint32_t>(), c->b_cls_idx.as<int32_t>(), c->b_plan.as<uint32_t>(), ncls + 1, st))) return rc;
-        PC_HIP(hipMemcpyAsync(c->h_plan, c->b_plan.p, (ncls + 1) * 4, hipMemcpyDeviceToHost, st));
+        if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(),
+                                        (int64_t)(c->b_scan_tmp.cap / 4), st))) return rc;
         uint64_t* h_tot = (uint64_t*)(c->h_plan + 1000);
         PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 24, hipMemcpyDeviceToHost, st));
-        PC_HIP(hipStreamSynchronize(st));
+        PC_HIP(hipStreamSynchronize(st));                                     // first read-back: the batch size
         const uint64_t A = h_tot[0];
         if (A >= 0x7fffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^31-1 per-call limit; shard the job (pc_set_shard)", (unsigned long long)A); return PC_ERR_LIMIT; }
-        const uint32_t ntasks = c->h_plan[ncls];
-        local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2]; local.n_tasks = ntasks;
-        if ((rc = c->b_bucket_row.ensure(std::max<uint64_t>(A, 1) * 4)) || (rc = c->b_bucket_dest.ensure(std::max<uint64_t>(A, 1) * 4)) ||
-            (rc = c->b_res.ensure(std::max<uint64_t>(A, 1) * 8)) || (rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))))
-            return rc;
-        // 4 ENUM
-        if ((rc = pc_launch_task_fill(c->b_cls_order.as<int32_t>(), c->b_col_cnt.as<uint32_t>(), c->b_task_rows.as<int32_t>(), c->b_start_q.as<uint32_t>(),
-                                      c->b_task_off_q.as<uint32_t>(), c->b_col_start.as<uint32_t>(), c->b_tasks.as<PcTask>(), G, st))) return rc;
-        PC_HIP(hipMemsetAsync(c->b_col_cur.p, 0, (G + 1) * 4, st));
-        a.off = c->b_off.as<uint32_t>(); a.col_start = c->b_col_start.as<uint32_t>(); a.col_cur = c->b_col_cur.as<uint32_t>();
-        a.bucket_row = c->b_bucket_row.as<int32_t>(); a.bucket_dest = c->b_bucket_dest.as<uint32_t>();
-        if ((rc = pc_launch_walk(PCW_ENUM, d, c->shard, a, st))) return rc;
-        PC_HIP(hipEventRecord(c->ev[1], st));
-        // 5 K4
-        std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
-        if ((rc = run_align_classes(c, tb.data(), st, &local, ppos))) return rc;
-        PC_HIP(hipEventRecord(c->ev[2], st));
-        // 6 REDUCE
-        a.res = c->b_res.as<uint2>(); a.out = out;
+        local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2];
+        a.off = c->b_off.as<uint32_t>();
+        if (A > 0) {
+            const int64_t An = (int64_t)A;
+            const int key_bits = 2 * d.ubits;
+            const size_t sort_bytes = pc_sort_temp_bytes(An, key_bits);
+            if ((rc = c->b_key0.ensure(A * 8)) || (rc = c->b_key1.ensure(A * 8)) || (rc = c->b_val0.ensure(A * 4)) || (rc = c->b_val1.ensure(A * 4)) ||
+                (rc = c->b_sort_tmp.ensure(std::max<size_t>(sort_bytes, 16))) || (rc = c->b_flags.ensure((A + 1) * 4)) || (rc = c->b_excl.ensure((A + 1) * 4)) ||
+                (rc = c->b_alias.ensure(A * 4)) || (rc = c->b_bucket_row.ensure(A * 4)) || (rc = c->b_res.ensure(A * 8)) ||
+                (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(std::max<int64_t>(tmp_fixed, An + 1)) * 4)))
+                return rc;
+            const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
+            // 2 ENUM: one sort key per alignment slot; 3 sort; 4 distinct alignments, aliases, buckets (pc_plan.hip)
+            a.key = c->b_key0.as<unsigned long long>(); a.val = c->b_val0.as<uint32_t>();
+            if ((rc = pc_launch_walk(PCW_ENUM, d, c->shard, a, st))) return rc;
+            if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
+                                    c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), An, key_bits, st))) return rc;
+            if ((rc = pc_launch_mark_heads(c->b_key1.as<unsigned long long>(), c->b_flags.as<uint32_t>(), An, st))) return rc;
+            if ((rc = pc_scan_exclusive_u32(c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(), An + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+            PC_HIP(hipMemsetAsync(c->b_start_q.p, 0, (U + 1) * 4, st));
+            PC_HIP(hipMemsetAsync(c->b_end_q.p, 0, (U + 1) * 4, st));
+            if ((rc = pc_launch_unique(d, c->b_key1.as<unsigned long long>(), c->b_val1.as<uint32_t>(), c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(),
+                                       c->b_alias.as<uint32_t>(), c->b_bucket_row.as<int32_t>(), c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(),
+                                       c->b_totals.as<unsigned long long>(), An, st))) return rc;
+            // 5 workgroup tasks per column sequence; second read-back: task range per launch class, distinct totals
+            if ((rc = pc_launch_task_count(c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->b_task_rows.as<int32_t>(), c->b_ntask_q.as<uint32_t>(), U, st))) return rc;
+            if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), U + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+            if ((rc = pc_launch_gather_u32(c->b_task_off_q.as<uint32_t>(), c->b_cls_idx.as<int32_t>(), c->b_plan.as<uint32_t>(), ncls + 1, st))) return rc;
+            PC_HIP(hipMemcpyAsync(c->h_plan, c->b_plan.p, (ncls + 1) * 4, hipMemcpyDeviceToHost, st));
+            PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 40, hipMemcpyDeviceToHost, st));
+            PC_HIP(hipStreamSynchronize(st));
+            const uint32_t ntasks = c->h_plan[ncls];
+            local.n_tasks = ntasks; local.n_distinct_alignments = (int64_t)h_tot[3]; local.n_distinct_cells = (int64_t)h_tot[4];
+            if ((rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask)))) return rc;
+            if ((rc = pc_launch_task_fill(d, c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->b_task_rows.as<int32_t>(),
+                                          c->b_task_off_q.as<uint32_t>(), c->b_tasks.as<PcTask>(), U, st))) return rc;
+            PC_HIP(hipEventRecord(c->ev[1], st));
+            // 6 K4: one result per distinct alignment, addressed by its position in the sorted list
+            std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
+            if ((rc = run_align_classes(c, tb.data(), st, &local, ppos))) return rc;
+            PC_HIP(hipEventRecord(c->ev[2], st));
+        } else {
+            PC_HIP(hipEventRecord(c->ev[1], st));
+            PC_HIP(hipEventRecord(c->ev[2], st));
+        }
+        // 7 REDUCE: best match per anchor gene through the aliases, fp64 epilogue
+        a.alias = c->b_alias.as<uint32_t>(); a.res = c->b_res.as<uint2>(); a.out = out;
         if ((rc = pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, d, c->shard, a, st))) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
     }
@@ -472,7 +517,7 @@ extern "C" int pc_fill(pc_ctx* c, int metric, int as_distance, double* out_conde
 extern "C" int pc_fill_shard_dev(pc_ctx* c, int metric, int as_distance, void* shard_dev, void* stream, pc_stats* stats) {
     if (!c || !c->uploaded) { pc_set_error("pc_fill_shard_dev: upload first"); return PC_ERR_STATE; }
     int rc = set_device(c); if (rc != PC_OK) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = (hipStream_t)stream;
     if (c->shard_stride > c->shard_pairs)
         PC_HIP(hipMemsetAsync((double*)shard_dev + c->shard_pairs, 0, (c->shard_stride - c->shard_pairs) * 8, st));
     return fill_impl(c, metric, as_distance, (double*)shard_dev, 0, st, stats);
@@ -483,7 +528,7 @@ extern "C" int pc_assemble_dev(pc_ctx* c, const void* gathered_dev, int world, v
     if (world != c->world) { pc_set_error("pc_assemble_dev: world %d != shard world %d", world, c->world); return PC_ERR_ARG; }
     int rc = set_device(c); if (rc != PC_OK) return rc;
     return pc_launch_assemble((const double*)gathered_dev, world, c->shard_stride, c->dev.N, (double*)out_condensed_dev,
-                              stream ? (hipStream_t)stream : c->stream);
+                              (hipStream_t)stream);
 }
 
 extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b_gene, int64_t n, int variant,

@@ -17,6 +17,7 @@
 // Device view of the uploaded genomes (all pointers are HBM).
 struct PcDev {
     int32_t N, Wb, Wstride, G;       // genomes, bitmap words per row, row stride in u64 (odd), genes
+    int32_t U, ubits;                 // distinct gene sequences; bits of a sequence rank (2^ubits >= U)
     int64_t E;                        // (genome, pham) entries
     const uint64_t* bitmap;           // [N][Wstride]
     const uint32_t* rankpre;          // [N][Wb]   entry index of the first set bit of word w of genome g
@@ -29,6 +30,8 @@ struct PcDev {
     const int32_t* nph;               // [N]
     const int32_t* ngen;              // [N]
     const int64_t* tlen;              // [N]
+    const uint32_t* gene_q;           // [G] rank of the gene's sequence among the distinct sequences, in launch-class order
+    const int32_t* q_gene;            // [U] a gene that carries sequence q (its first occurrence)
 };
 
 // Static shard: the target genomes this rank owns, ascending.
@@ -47,16 +50,14 @@ enum { PCW_POCP = 0, PCW_AF = 1, PCW_COUNT = 2, PCW_ENUM = 3, PCW_AAI = 4, PCW_P
 struct PcWalkArgs {
     // COUNT
     uint32_t* na;                     // [Lp] alignments per pair
-    uint32_t* col_cnt;                // [G]  alignments per column gene
-    unsigned long long* totals;       // [0] alignments [1] cells [2] residue bytes
-    // ENUM
+    unsigned long long* totals;       // [0] alignments [1] cells [2] residue bytes (as the reference would run them)
+    // ENUM: alignment slot k of a pair = off[pair] + its position in the reference's loop order
     const uint32_t* off;              // [Lp] exclusive scan of na
-    const uint32_t* col_start;        // [G]
-    uint32_t* col_cur;                // [G] zeroed
-    int32_t* bucket_row;              // [A] row gene
-    uint32_t* bucket_dest;            // [A] pair-major result slot
+    unsigned long long* key;          // [A] (column sequence rank << ubits) | row sequence rank
+    uint32_t* val;                    // [A] k
     // AAI / PEQ
-    const uint2* res;                 // [A] (n_ident, aln_len)
+    const uint32_t* alias;            // [A] slot -> index of its distinct (row sequence, column sequence) alignment
+    const uint2* res;                 // [distinct alignments] (n_ident, aln_len)
     // output (POCP, AF, AAI, PEQ)
     double* out;
     int as_distance;
@@ -78,9 +79,16 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
-int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st);
-int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, const uint32_t* start_q, const uint32_t* task_off_q,
-                        uint32_t* col_start, PcTask* tasks, int G, hipStream_t st);
+// planning of the alignment batch (pc_plan.hip)
+size_t pc_sort_temp_bytes(int64_t n, int bits);
+int pc_sort_pairs(void* temp, size_t temp_bytes, const unsigned long long* key_in, unsigned long long* key_out, const uint32_t* val_in,
+                  uint32_t* val_out, int64_t n, int bits, hipStream_t st);
+int pc_launch_mark_heads(const unsigned long long* skey, uint32_t* flags, int64_t n, hipStream_t st);
+int pc_launch_unique(const PcDev& d, const unsigned long long* skey, const uint32_t* sval, const uint32_t* flags, const uint32_t* excl,
+                     uint32_t* alias, int32_t* bucket_row, uint32_t* start_q, uint32_t* end_q, unsigned long long* totals, int64_t n, hipStream_t st);
+int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, uint32_t* ntask_q, int U, hipStream_t st);
+int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, const uint32_t* task_off_q,
+                        PcTask* tasks, int U, hipStream_t st);
 int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st);
 int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st);
 int pc_launch_round6_probe(const double* in, double* out, int64_t n, hipStream_t st);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
         }
         if (active) {
             const uint32_t ident = final_stat & 0xffffu, ndiag = final_stat >> 16;
-            res[bucket_dest[row]] = make_uint2(ident, (uint32_t)(la + lb) - ndiag);
+            res[bucket_dest ? bucket_dest[row] : (uint32_t)row] = make_uint2(ident, (uint32_t)(la + lb) - ndiag);
         }
       }
     }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
             if ((a & PCF_LAST) && is_out) {
                 const uint32_t st = PcPick<W, 0>::get(SHu, c_out);
-                res[bucket_dest[tk.begin + task_row(out_r)]] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
+                res[bucket_dest ? bucket_dest[tk.begin + task_row(out_r)] : (uint32_t)(tk.begin + task_row(out_r))] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
                 out_r += nseg;
             }
         }

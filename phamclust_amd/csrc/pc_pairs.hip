@@ -246,24 +246,24 @@ __device__ __forceinline__ void pc_visit(const PcDev& d, const PcWalkArgs& a, Pc
     const int a0 = d.ent_gene[ea], b0 = d.ent_gene[eb];
     if (MODE == PCW_COUNT) {
         p.k += (uint32_t)(ca * cb);
-        for (int ib = 0; ib < cb; ++ib) atomicAdd(&a.col_cnt[b0 + ib], (uint32_t)ca);
         const unsigned long long la = (unsigned long long)d.ent_len[ea], lb = (unsigned long long)d.ent_len[eb];
         cells += la * lb;
         rbytes += la * cb + lb * ca;
-    } else if (MODE == PCW_ENUM) {
-        for (int ia = 0; ia < ca; ++ia)
+    } else if (MODE == PCW_ENUM) {                                                        // sort key per alignment slot (pc_plan.hip)
+        for (int ia = 0; ia < ca; ++ia) {
+            const unsigned long long qa = d.gene_q[a0 + ia];
             for (int ib = 0; ib < cb; ++ib) {
-                const int b = b0 + ib;
-                const uint32_t pos = a.col_start[b] + atomicAdd(&a.col_cur[b], 1u);
-                a.bucket_row[pos] = a0 + ia;
-                a.bucket_dest[pos] = p.k++;
+                const uint32_t k = p.k++;
+                a.key[k] = ((unsigned long long)d.gene_q[b0 + ib] << d.ubits) | qa;
+                a.val[k] = k;
             }
+        }
     } else {                                                                              // AAI / PEQ
         if (MODE == PCW_PEQ) p.cons += d.ent_len[es] + d.ent_len[et];
         for (int ia = 0; ia < ca; ++ia) {
             double best = -1.0; uint32_t best_len = 0;
             for (int ib = 0; ib < cb; ++ib) {
-                const uint2 r = a.res[p.k++];
+                const uint2 r = a.res[a.alias[p.k++]];
                 const double x = (double)r.x / (double)r.y;                               // metrics.py:221
                 if (x >= best) { best = x; best_len = r.y; }                              // sorted(...)[-1] (metrics.py:223)
             }
@@ -434,46 +434,6 @@ int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("scan launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
-}
-
-// ---------------------------------------------------------------------------------
-// Wave-task building.  Genes are visited in class order (grouped by kernel variant).
-// ---------------------------------------------------------------------------------
-__global__ void k_task_count(const int32_t* __restrict__ cls_order, const uint32_t* __restrict__ col_cnt,
-                             const int32_t* __restrict__ task_rows, uint32_t* __restrict__ cnt_q, uint32_t* __restrict__ ntask_q, int G) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > G) return;
-    const int g = q < G ? cls_order[q] : 0;
-    const uint32_t n = q < G ? col_cnt[g] : 0u, per = q < G ? (uint32_t)task_rows[g] : 1u;
-    cnt_q[q] = n;
-    ntask_q[q] = (n + per - 1) / per;
-}
-
-__global__ void k_task_fill(const int32_t* __restrict__ cls_order, const uint32_t* __restrict__ col_cnt,
-                            const int32_t* __restrict__ task_rows, const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ task_off_q,
-                            uint32_t* __restrict__ col_start, PcTask* __restrict__ tasks, int G) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= G) return;
-    const int g = cls_order[q];
-    const uint32_t n = col_cnt[g], st = start_q[q];
-    col_start[g] = st;
-    uint32_t to = task_off_q[q];
-    const uint32_t per = (uint32_t)task_rows[g];
-    for (uint32_t r = 0; r < n; r += per) {
-        PcTask t; t.gene = g; t.begin = (int32_t)(st + r); t.end = (int32_t)(st + min(n, r + per)); t.pad = 0;
-        tasks[to++] = t;
-    }
-}
-
-int pc_launch_task_count(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, uint32_t* cnt_q, uint32_t* ntask_q, int G, hipStream_t st) {
-    hipLaunchKernelGGL(k_task_count, dim3((G + 1 + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, task_rows, cnt_q, ntask_q, G);
-    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
-}
-int pc_launch_task_fill(const int32_t* cls_order, const uint32_t* col_cnt, const int32_t* task_rows, const uint32_t* start_q, const uint32_t* task_off_q,
-                        uint32_t* col_start, PcTask* tasks, int G, hipStream_t st) {
-    if (G <= 0) return PC_OK;
-    hipLaunchKernelGGL(k_task_fill, dim3((G + 255) / 256), dim3(256), 0, st, cls_order, col_cnt, task_rows, start_q, task_off_q, col_start, tasks, G);
-    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
 __global__ void k_gather_u32(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, uint32_t* __restrict__ dst, int n) {

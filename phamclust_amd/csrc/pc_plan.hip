@@ -1,0 +1,129 @@
+// pc_plan.hip -- planning of one fill's alignment batch (aai / peq).
+//
+// The pair walk (pc_pairs.hip, mode ENUM) writes one 64-bit key per alignment the reference would run
+// (metrics.py:211-217): (rank of the column sequence << ubits) | rank of the row sequence, ranks taken over the
+// DISTINCT gene sequences of the upload in launch-class order.  A radix sort of (key, slot) then does three jobs
+// at once:
+//   * equal keys become adjacent: each distinct (row sequence, column sequence) pair is aligned once and every
+//     slot that asked for it gets an alias to the one result (phage genomes share many identical proteins;
+//     the alignment depends on the two sequences only);
+//   * the distinct alignments of one column sequence are contiguous: that run is the column's bucket, cut into
+//     workgroup tasks that share the column's profile;
+//   * buckets come out in launch-class order, so each kernel variant's tasks are one contiguous range.
+// No atomics: bucket contents and order are a pure function of the input.
+// The sort is rocPRIM's (33.5 M pairs, 40 key bits: 1.6 ms on MI355X); the rest are small kernels below.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/phamclust_hip.h"
+#include "pc_common.h"
+
+size_t pc_sort_temp_bytes(int64_t n, int bits) {
+    size_t bytes = 0;
+    if (n <= 0) return 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t)0);
+    return e == hipSuccess ? bytes : 0;
+}
+
+int pc_sort_pairs(void* temp, size_t temp_bytes, const unsigned long long* key_in, unsigned long long* key_out, const uint32_t* val_in,
+                  uint32_t* val_out, int64_t n, int bits, hipStream_t st) {
+    if (n <= 0) return PC_OK;
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, key_in, key_out, val_in, val_out, (size_t)n, 0u, (unsigned)bits, st);
+    if (e != hipSuccess) { pc_set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// flags[i] = 1 where sorted position i starts a run of equal keys; flags[n] = 0 (so that a scan over n+1 elements
+// leaves the number of distinct keys in its last slot)
+__global__ __launch_bounds__(256) void k_mark_heads(const unsigned long long* __restrict__ skey, uint32_t* __restrict__ flags, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    flags[i] = (i < n && (i == 0 || skey[i] != skey[i - 1])) ? 1u : 0u;
+}
+int pc_launch_mark_heads(const unsigned long long* skey, uint32_t* flags, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_mark_heads, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, skey, flags, n);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+
+// Sorted position i belongs to distinct alignment u = excl[i] + flags[i] - 1.  Every slot learns its alias; the
+// head of a run records the row gene of alignment u and, where the column sequence changes, the bucket bounds
+// [start_q, end_q) of that column (both zero-initialised: a column nobody aligns against keeps an empty bucket).
+// totals[3] += distinct alignments, totals[4] += their cells.
+__global__ __launch_bounds__(256) void k_unique(PcDev d, const unsigned long long* __restrict__ skey, const uint32_t* __restrict__ sval,
+                                                const uint32_t* __restrict__ flags, const uint32_t* __restrict__ excl,
+                                                uint32_t* __restrict__ alias, int32_t* __restrict__ bucket_row,
+                                                uint32_t* __restrict__ start_q, uint32_t* __restrict__ end_q,
+                                                unsigned long long* __restrict__ totals, int64_t n) {
+    __shared__ unsigned long long red[2];
+    if (threadIdx.x < 2) red[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cells = 0, heads = 0;
+    if (i < n) {
+        const uint32_t f = flags[i], u = excl[i] + f - 1u;
+        alias[sval[i]] = u;
+        if (f) {
+            const unsigned long long key = skey[i];
+            const uint32_t qa = (uint32_t)(key & ((1ull << d.ubits) - 1)), qb = (uint32_t)(key >> d.ubits);
+            const int ga = d.q_gene[qa];
+            bucket_row[u] = ga;
+            cells = (unsigned long long)d.gene_len[ga] * (unsigned long long)d.gene_len[d.q_gene[qb]];
+            heads = 1;
+            // position i-1 carries the key of the previous distinct alignment (runs hold equal keys): where the column
+            // changes, this alignment opens its column's bucket and closes the previous column's
+            if (i == 0) start_q[qb] = 0;
+            else {
+                const uint32_t qp = (uint32_t)(skey[i - 1] >> d.ubits);
+                if (qp != qb) { start_q[qb] = u; end_q[qp] = u; }
+            }
+        }
+        if (i == n - 1) end_q[(uint32_t)(skey[i] >> d.ubits)] = u + 1;      // the last column's bucket ends with the list
+    }
+    for (int o = 32; o > 0; o >>= 1) { cells += __shfl_down(cells, o); heads += __shfl_down(heads, o); }
+    if ((threadIdx.x & 63) == 0 && heads) { atomicAdd(&red[0], heads); atomicAdd(&red[1], cells); }
+    __syncthreads();
+    if (threadIdx.x < 2 && red[threadIdx.x]) atomicAdd(&totals[3 + threadIdx.x], red[threadIdx.x]);
+}
+int pc_launch_unique(const PcDev& d, const unsigned long long* skey, const uint32_t* sval, const uint32_t* flags, const uint32_t* excl,
+                     uint32_t* alias, int32_t* bucket_row, uint32_t* start_q, uint32_t* end_q, unsigned long long* totals, int64_t n, hipStream_t st) {
+    if (n <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_unique, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, skey, sval, flags, excl, alias, bucket_row, start_q, end_q, totals, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_unique launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// Workgroup tasks per column sequence q (ntask_q has U+1 slots, the last one zero, for the scan's total)
+__global__ void k_task_count(const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q, const int32_t* __restrict__ task_rows,
+                             uint32_t* __restrict__ ntask_q, int U) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > U) return;
+    uint32_t nt = 0;
+    if (q < U) { const uint32_t n = end_q[q] - start_q[q], per = (uint32_t)task_rows[q]; nt = (n + per - 1) / per; }
+    ntask_q[q] = nt;
+}
+int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, uint32_t* ntask_q, int U, hipStream_t st) {
+    hipLaunchKernelGGL(k_task_count, dim3((U + 1 + 255) / 256), dim3(256), 0, st, start_q, end_q, task_rows, ntask_q, U);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+
+__global__ void k_task_fill(PcDev d, const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q,
+                            const int32_t* __restrict__ task_rows, const uint32_t* __restrict__ task_off_q, PcTask* __restrict__ tasks, int U) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= U) return;
+    const uint32_t b = start_q[q], e = end_q[q], per = (uint32_t)task_rows[q];
+    uint32_t to = task_off_q[q];
+    const int gene = d.q_gene[q];
+    for (uint32_t r = b; r < e; r += per) {
+        PcTask t; t.gene = gene; t.begin = (int32_t)r; t.end = (int32_t)min(e, r + per); t.pad = 0;
+        tasks[to++] = t;
+    }
+}
+int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, const uint32_t* task_off_q,
+                        PcTask* tasks, int U, hipStream_t st) {
+    if (U <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_task_fill, dim3((U + 255) / 256), dim3(256), 0, st, d, start_q, end_q, task_rows, task_off_q, tasks, U);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}

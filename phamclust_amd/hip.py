@@ -35,7 +35,7 @@ class PcStats(ctypes.Structure):
                 ("n_tasks", ctypes.c_int64), ("n_residue_bytes", ctypes.c_int64),
                 ("n_align_launches", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("ms_total", ctypes.c_float), ("ms_plan", ctypes.c_float), ("ms_align", ctypes.c_float),
-                ("ms_reduce", ctypes.c_float)]
+                ("ms_reduce", ctypes.c_float), ("n_distinct_alignments", ctypes.c_int64), ("n_distinct_cells", ctypes.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}

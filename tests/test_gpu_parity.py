@@ -281,6 +281,35 @@ def test_matrix_de_novo_drop_in(native_built, small_genomes):
     assert METRICS["peq"](s, t, as_distance=True) == m.get_weight(s.name, t.name)
 
 
+def test_redundant_sequences_are_aligned_once(gpu_ctx, native_built):
+    """Genomes that share identical proteins (clones, clones with a few genes changed, paralogs with the same
+    sequence): the plan aligns each distinct (row sequence, column sequence) pair once and aliases the rest, and
+    every value still equals the oracle, which aligns them all (metrics.py:211-217)."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    from phamclust_amd.synth import synth_genomes
+    O = _oracle()
+    base = synth_genomes(24, 300, seed=11)
+    genomes = list(base)
+    for i, g in enumerate(base[:12]):                       # exact clones and near-clones
+        clone, near = Genome(f"clone_{i:02d}"), Genome(f"near_{i:02d}")
+        for j, (pham, translations) in enumerate(g):
+            for t in translations:
+                clone.add(pham, t)
+                near.add(pham, t if j % 5 else t[:-3] + "WWW")
+            if j % 7 == 0:
+                near.add(pham, translations[0])             # a paralog with an identical sequence
+        genomes += [clone, near]
+    genomes.sort(key=lambda g: g.name)
+    packed = pack_genomes(genomes)
+    for metric in ("aai", "peq"):
+        got, st = gpu_ctx.upload(packed).fill(metric, as_distance=True, want_stats=True)
+        assert np.array_equal(got, O.fill(packed, metric, as_distance=True))
+        assert 0 < st["n_distinct_alignments"] < 0.7 * st["n_alignments"] and st["n_distinct_cells"] < st["n_cells"]
+    got, st = gpu_ctx.upload(pack_genomes(base)).fill("peq", want_stats=True)      # the synthetic set itself: next to nothing aliased
+    assert 0.99 * st["n_alignments"] < st["n_distinct_alignments"] <= st["n_alignments"] and st["n_distinct_cells"] <= st["n_cells"]
+
+
 @pytest.mark.parametrize("metric", SET_METRICS)
 def test_full_size_set_metrics_vs_oracle(gpu_ctx, native_built, metric):
     """BASELINE configs[1] at full size (synth(2000,5000): 1,999,000 pairs): every value against the oracle."""
@@ -322,7 +351,8 @@ def test_full_size_peq_properties(gpu_ctx, native_built):
         gpu_ctx.fill_shard_dev("peq", True, buf.data_ptr(), stream)
         parts.append(buf)
     out = torch.empty(packed.n_pairs, dtype=torch.float64, device="cuda:0")
-    gpu_ctx.assemble_dev(torch.cat(parts).data_ptr(), 8, out.data_ptr(), stream)
+    gathered = torch.cat(parts)                          # queued on torch's stream; the assembly below runs on the same one
+    gpu_ctx.assemble_dev(gathered.data_ptr(), 8, out.data_ptr(), stream)
     torch.cuda.synchronize()
     gpu_ctx.set_shard(0, 1)
     assert np.array_equal(out.cpu().numpy(), dist)

@@ -243,8 +243,8 @@ def test_abi_exports_match_header(native_built):
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().pc_version() == 100
-    assert ctypes.sizeof(hip.PcPacked) == 16 + 8 * 8 and ctypes.sizeof(hip.PcStats) == 5 * 8 + 2 * 4 + 4 * 4
+    assert hip.load().pc_version() == 110
+    assert ctypes.sizeof(hip.PcPacked) == 16 + 8 * 8 and ctypes.sizeof(hip.PcStats) == 5 * 8 + 2 * 4 + 4 * 4 + 2 * 8
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -27,10 +27,10 @@ for i in range(a.steps):
     t0 = time.time()
     out, st = ctx.fill(a.m, True, want_stats=True)
     dt = time.time() - t0
-    gc = st["n_cells"] / max(st["ms_align"], 1e-9) / 1e6 if st["n_cells"] else 0.0
+    gc = st["n_distinct_cells"] / max(st["ms_align"], 1e-9) / 1e6 if st["n_distinct_cells"] else 0.0
     print(f"step {i}: wall {dt * 1e3:.1f} ms dev {st['ms_total']:.2f} ms plan {st['ms_plan']:.2f} align {st['ms_align']:.2f} "
           f"reduce {st['ms_reduce']:.2f} | pairs/s {pk.n_pairs / dt:.3e} | aln {st['n_alignments']} cells {st['n_cells']:.3e} "
-          f"tasks {st['n_tasks']} launches {st['n_align_launches']} GCUPS {gc:.1f}", flush=True)
+          f"distinct aln {st['n_distinct_alignments']} cells {st['n_distinct_cells']:.3e} tasks {st['n_tasks']} launches {st['n_align_launches']} GCUPS {gc:.1f}", flush=True)
 if a.check:
     from oracle import oracle as O
     rng = np.random.default_rng(1)

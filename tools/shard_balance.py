@@ -27,7 +27,8 @@ for r in range(world):
     parts.append(buf); rows.append(s)
     print(f"rank {r}: pairs {s['n_pairs']} aln {s['n_alignments']} cells {s['n_cells']:.4e} ms {s['ms_total']:.1f} (plan {s['ms_plan']:.1f} align {s['ms_align']:.1f})", flush=True)
 out = torch.empty(pk.n_pairs, dtype=torch.float64, device="cuda")
-ctx.assemble_dev(torch.cat(parts).data_ptr(), world, out.data_ptr(), stream); torch.cuda.synchronize()
+gathered = torch.cat(parts)
+ctx.assemble_dev(gathered.data_ptr(), world, out.data_ptr(), stream); torch.cuda.synchronize()
 cells = np.array([s["n_cells"] for s in rows], float); ms = np.array([s["ms_total"] for s in rows])
 print(f"assembled == unsharded: {bool(torch.equal(out, full))}")
 print(f"cells max/mean {cells.max() / cells.mean():.4f}; ms max/mean {ms.max() / ms.mean():.4f}; sum of rank ms {ms.sum():.1f} vs unsharded {st['ms_total']:.1f}; "
