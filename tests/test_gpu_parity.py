@@ -435,3 +435,12 @@ def test_bench_two_ranks_rehearsal(native_built):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["genome_pairs"] == 301 * 300 // 2 and "REHEARSAL" in d["config"]["parallelism"]
     assert d["verified"]["bit_exact"] is True and d["roofline"]["n_alignments"] > 0
+
+
+def test_graft_entry_smoke(native_built):
+    """The driver's smoke(): all six metrics on a small synthetic set against the oracle."""
+    import importlib
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    importlib.import_module("__graft_entry__").smoke()

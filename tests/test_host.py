@@ -243,7 +243,7 @@ def test_abi_exports_match_header(native_built):
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().pc_version() == 110
+    assert hip.load().pc_version() == int(re.search(r"#define\s+PC_VERSION\s+(\d+)", header).group(1)) >= 110
     assert ctypes.sizeof(hip.PcPacked) == 16 + 8 * 8 and ctypes.sizeof(hip.PcStats) == 5 * 8 + 2 * 4 + 4 * 4 + 2 * 8
 
 
@@ -265,3 +265,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".c")):
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "pc_oracle" not in text, f
+
+
+def test_graft_entry_build(native_built):
+    """The driver's build check (`__graft_entry__.build()`): compiles what is stale, imports the package, and
+    agrees with the header about the ABI version."""
+    import importlib
+    sys.path.insert(0, REPO)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
