@@ -271,6 +271,7 @@ def test_graft_entry_build(native_built):
     """The driver's build check (`__graft_entry__.build()`): compiles what is stale, imports the package, and
     agrees with the header about the ABI version."""
     import importlib
+    import sys
     sys.path.insert(0, REPO)
     entry = importlib.import_module("__graft_entry__")
     entry.build()
