@@ -306,6 +306,17 @@ def test_redundant_sequences_are_aligned_once(gpu_ctx, native_built):
         got, st = gpu_ctx.upload(packed).fill(metric, as_distance=True, want_stats=True)
         assert np.array_equal(got, O.fill(packed, metric, as_distance=True))
         assert 0 < st["n_distinct_alignments"] < 0.7 * st["n_alignments"] and st["n_distinct_cells"] < st["n_cells"]
+    clones = []                                             # 40 copies of one genome: one distinct alignment per gene
+    for i in range(40):
+        g = Genome(f"same_{i:02d}")
+        for pham, translations in base[0]:
+            for t in translations:
+                g.add(pham, t)
+        clones.append(g)
+    packed = pack_genomes(clones)
+    got, st = gpu_ctx.upload(packed).fill("peq", as_distance=False, want_stats=True)
+    assert np.array_equal(got, O.fill(packed, "peq", as_distance=False)) and (got == 1.0).all()
+    assert st["n_alignments"] >= 780 * st["n_distinct_alignments"] > 0
     got, st = gpu_ctx.upload(pack_genomes(base)).fill("peq", want_stats=True)      # the synthetic set itself: next to nothing aliased
     assert 0.99 * st["n_alignments"] < st["n_distinct_alignments"] <= st["n_alignments"] and st["n_distinct_cells"] <= st["n_cells"]
 
