@@ -189,6 +189,39 @@ def test_edge_cases(gpu_ctx, native_built):
     assert gpu_ctx.fill("af", as_distance=False)[0] == 1.0
 
 
+def test_random_small_sets_all_metrics(gpu_ctx, native_built):
+    """150 random little collections (2-9 genomes, few phams so that sharing, paralogs and byte-identical
+    sequences are common; lengths 1-90; residues drawn from the alphabet plus B Z X * U, lower case and '-'):
+    all six metrics, both polarities, against the oracle.  Exercises the plan's corner cases (one alignment,
+    one distinct sequence, every alignment identical, single-row buckets)."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(2024)
+    letters = np.array(list("ACDEFGHIKLMNPQRSTVWY" * 3 + "BZX*Uacdw-"))
+    for trial in range(150):
+        n_genomes, n_phams = int(rng.integers(2, 10)), int(rng.integers(1, 7))
+        pool = ["".join(letters[rng.integers(0, letters.size, int(rng.integers(1, 91)))]) for _ in range(int(rng.integers(1, 8)))]
+        genomes = []
+        for g in range(n_genomes):
+            genome = Genome(f"g{g:02d}")
+            for p in rng.permutation(n_phams)[:int(rng.integers(1, n_phams + 1))]:
+                for _ in range(int(rng.integers(1, 4)) if rng.random() < 0.3 else 1):
+                    seq = pool[int(rng.integers(0, len(pool)))]
+                    if rng.random() < 0.4:                                   # a point mutant or a truncation of a pool member
+                        cut = int(rng.integers(0, len(seq)))
+                        seq = seq[:cut] + "W" + seq[cut + 1:] if rng.random() < 0.5 else seq[:max(1, cut)]
+                    genome.add(f"pham{p}", seq)
+            genomes.append(genome)
+        packed = pack_genomes(genomes)
+        gpu_ctx.upload(packed)
+        for metric in ALL_METRICS:
+            for as_distance in (True, False):
+                got = gpu_ctx.fill(metric, as_distance=as_distance)
+                want = O.fill(packed, metric, as_distance=as_distance)
+                assert np.array_equal(got, want), (trial, metric, as_distance)
+
+
 def test_long_and_ragged_sequences(gpu_ctx, native_built):
     """Column sequences from 1 residue up to beyond the systolic kernels' reach."""
     from phamclust_amd.genome import Genome
