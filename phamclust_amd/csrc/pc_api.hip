@@ -16,9 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
-#include <string_view>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "pc_common.h"
@@ -46,6 +46,16 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
+
+// fn(begin, end) over [0, n) on up to 16 host threads (upload-time indexing of ~10^8 residues)
+template <class F> void parallel_chunks(int64_t n, F fn) {
+    int nt = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), (n + 4095) / 4096);
+    if (nt <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) th.emplace_back([=] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    for (auto& x : th) x.join();
+}
 
 template <class T> int upload_vec(DevBuf& b, const std::vector<T>& v) {
     int rc = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
@@ -192,6 +202,14 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         pc_set_error("pc_upload: bad gene table"); return PC_ERR_ARG;
     }
     const int G = (int)G64;
+    static const bool timing = getenv("PC_UPLOAD_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "pc_upload %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     c->uploaded = false;
     PC_HIP(hipStreamSynchronize(c->stream));
 
@@ -235,36 +253,57 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
             pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG;
         }
     }
-    std::vector<uint8_t> codes((size_t)std::max<int64_t>(code_bytes, 16), (uint8_t)PC_PADCODE);
+    lap("entries, rank table");
+    // encoded residues (16-byte padded per gene) and a 64-bit hash of each gene's codes, on several host threads
+    std::vector<uint8_t> codes((size_t)std::max<int64_t>(code_bytes, 16));
+    std::vector<uint64_t> ghash(std::max(G, 1));
     uint8_t lut[256]; build_code_lut(lut);
-    for (int k = 0; k < G; ++k) {
-        const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
-        for (int i = 0; i < gene_len[k]; ++i) dst[i] = lut[src[i]];
-    }
+    parallel_chunks(G, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
+            const int len = gene_len[k], padded = (len + 15) & ~15;
+            uint64_t h = 0x9e3779b97f4a7c15ULL ^ (uint64_t)len;
+            for (int i = 0; i < len; ++i) { const uint8_t cd = lut[src[i]]; dst[i] = cd; h = (h ^ cd) * 0x100000001b3ULL; }
+            for (int i = len; i < padded; ++i) dst[i] = (uint8_t)PC_PADCODE;
+            ghash[k] = h ^ (h >> 29);
+        }
+    });
+    lap("residue codes");
     // distinct sequences (by encoded residues: what the kernels compare).  Alignments are planned per distinct
     // (row sequence, column sequence) pair, so every sequence gets a rank q; ranks follow launch-class order: column
     // sequences grouped by the kernel variant that aligns against them and by lanes-per-segment bucket (the
     // profile's LDS footprint scales with it, and LDS sets occupancy)
     std::vector<int32_t> uid(G), u_gene;
-    {
-        std::unordered_map<std::string_view, int32_t> seen;
-        seen.reserve((size_t)G * 2 + 16);
+    {   // open-addressing table over the precomputed hashes; equal hash and length are confirmed by comparing the codes
+        size_t cap = 16;
+        while (cap < (size_t)G * 2) cap <<= 1;
+        std::vector<int32_t> slot(cap, -1);
         for (int k = 0; k < G; ++k) {
-            const std::string_view sv((const char*)&codes[(size_t)gene_off[k]], (size_t)gene_len[k]);
-            auto it = seen.emplace(sv, (int32_t)u_gene.size());
-            if (it.second) u_gene.push_back(k);
-            uid[k] = it.first->second;
+            size_t pos = (size_t)ghash[k] & (cap - 1);
+            for (;; pos = (pos + 1) & (cap - 1)) {
+                const int32_t u = slot[pos];
+                if (u < 0) { slot[pos] = (int32_t)u_gene.size(); uid[k] = (int32_t)u_gene.size(); u_gene.push_back(k); break; }
+                const int r = u_gene[u];
+                if (ghash[r] == ghash[k] && gene_len[r] == gene_len[k] &&
+                    !memcmp(&codes[(size_t)gene_off[r]], &codes[(size_t)gene_off[k]], (size_t)gene_len[k])) { uid[k] = u; break; }
+            }
         }
     }
     const int U = (int)u_gene.size();
+    lap("distinct sequences");
     const int nvar = pc_nw_num_variants();
     const int ncls_all = nvar * 4 + 1;                 // last class: general kernel
-    std::vector<int> u_cls(U);
+    std::vector<int> u_cls(U), len_cls(maxlen + 1, -1), len_rows(maxlen + 1, 0);     // per length: class, rows per task
     std::vector<int64_t> cls_count(ncls_all, 0);
     std::vector<int> cls_maxlb(ncls_all, 0);
     for (int u = 0; u < U; ++u) {
         const int len = gene_len[u_gene[u]];
-        const int cls = pc_class_of(len, pc_nw_choose_variant(len));
+        if (len_cls[len] < 0) {
+            const int variant = pc_nw_choose_variant(len);
+            len_cls[len] = pc_class_of(len, variant);
+            len_rows[len] = pc_nw_task_rows(len, variant);
+        }
+        const int cls = len_cls[len];
         u_cls[u] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], len);
     }
     c->cls_variant.clear(); c->cls_begin.clear(); c->cls_max_lb.clear();
@@ -284,13 +323,14 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         const int q = (int)cls_pos[u_cls[u]]++;
         const int len = gene_len[u_gene[u]];
         q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];
-        task_rows[q] = pc_nw_task_rows(len, u_cls[u] == ncls_all - 1 ? -1 : u_cls[u] / 4);
+        task_rows[q] = len_rows[len];
     }
     for (int k = 0; k < G; ++k) gene_q[k] = q_of_u[uid[k]];
     int ubits = 1;
     while ((1LL << ubits) < U) ++ubits;
     if (c->cls_begin.size() > 900) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // h_plan: 1000 u32, then the totals
 
+    lap("launch classes");
     // ---- device copies ---------------------------------------------------------------
     std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
     std::vector<int64_t> tlen(g->tlen, g->tlen + N);
@@ -313,6 +353,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     for (int s2 = 0; s2 < N; ++s2) c->max_nph = std::max(c->max_nph, (int)g->nph[s2]);
     rc = apply_shard(c, 0, 1);
     if (rc != PC_OK) return rc;
+    lap("device copies");
     c->uploaded = true;
     return PC_OK;
 }
