@@ -86,7 +86,7 @@ struct pc_ctx {
     DevBuf b_gene_q, b_q_gene, b_cls_idx, b_task_rows, b_owned, b_lbase;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
-    DevBuf b_tasks, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
+    DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -127,7 +127,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
                       &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
-                      &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_bucket_row, &c->b_bucket_dest,
+                      &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_tasks_sorted, &c->b_bucket_row, &c->b_bucket_dest,
                       &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -372,7 +372,7 @@ extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? 
 // Step 5 of the plan: launch the alignment kernels for every class that has tasks.  Classes are
 // independent (disjoint result slots), so their launches are spread over the caller's stream and
 // seven auxiliary streams: the drain of one class overlaps the next one's start.
-static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats, int ppos) {
+static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats, int ppos) {
     const int ncls = (int)c->cls_variant.size();
     std::vector<int> order;
     for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
@@ -401,7 +401,7 @@ static int run_align_classes(pc_ctx* c, const uint32_t* task_begin /*[ncls+1]*/,
         const int variant = ppos ? -1 : c->cls_variant[i];        // percent-positives: general kernel (rare, no CLI route)
         // launches that use the one scratch slab stay in order on the caller's stream
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
-        int rc = pc_launch_nw(variant, c->dev, c->b_tasks.as<PcTask>() + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
+        int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
                               nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
                               variant < 0 ? c->b_scratch.cap : 0, c->cls_max_lb[i], ppos, ls);
         if (rc != PC_OK) return rc;
@@ -509,10 +509,27 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
             if ((rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask)))) return rc;
             if ((rc = pc_launch_task_fill(d, c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->b_task_rows.as<int32_t>(),
                                           c->b_task_off_q.as<uint32_t>(), c->b_tasks.as<PcTask>(), U, st))) return rc;
+            // longest tasks first inside every launch class (same radix sort; key/value buffers of the alignment sort are free again)
+            static const bool sort_tasks = !(getenv("PC_TASK_ORDER") && !strcmp(getenv("PC_TASK_ORDER"), "plain"));
+            const PcTask* task_list = c->b_tasks.as<PcTask>();
+            if (sort_tasks && ntasks > 1) {
+                int cbits = 1; while ((1 << cbits) < ncls) ++cbits;
+                const size_t tb_bytes = pc_sort_temp_bytes((int64_t)ntasks, 32 + cbits);
+                if ((rc = c->b_tasks_sorted.ensure((size_t)ntasks * sizeof(PcTask))) || (rc = c->b_key0.ensure((size_t)ntasks * 8)) ||
+                    (rc = c->b_key1.ensure((size_t)ntasks * 8)) || (rc = c->b_val0.ensure((size_t)ntasks * 4)) || (rc = c->b_val1.ensure((size_t)ntasks * 4)) ||
+                    (rc = c->b_sort_tmp.ensure(std::max<size_t>(tb_bytes, 16))))
+                    return rc;
+                if ((rc = pc_launch_task_keys(d, c->b_tasks.as<PcTask>(), c->b_cls_idx.as<int32_t>(), ncls, c->b_key0.as<unsigned long long>(),
+                                              c->b_val0.as<uint32_t>(), (int)ntasks, st))) return rc;
+                if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
+                                        c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), (int64_t)ntasks, 32 + cbits, st))) return rc;
+                if ((rc = pc_launch_task_gather(c->b_tasks.as<PcTask>(), c->b_val1.as<uint32_t>(), c->b_tasks_sorted.as<PcTask>(), (int)ntasks, st))) return rc;
+                task_list = c->b_tasks_sorted.as<PcTask>();
+            }
             PC_HIP(hipEventRecord(c->ev[1], st));
             // 6 K4: one result per distinct alignment, addressed by its position in the sorted list
             std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
-            if ((rc = run_align_classes(c, tb.data(), st, &local, ppos))) return rc;
+            if ((rc = run_align_classes(c, task_list, tb.data(), st, &local, ppos))) return rc;
             PC_HIP(hipEventRecord(c->ev[2], st));
         } else {
             PC_HIP(hipEventRecord(c->ev[1], st));

@@ -42,7 +42,7 @@ struct PcShard {
 };
 
 // One wave task of the alignment kernels: column gene + a range of its bucket.
-struct PcTask { int32_t gene, begin, end, pad; };
+struct PcTask { int32_t gene, begin, end, pad; };   // pad: the column's sequence rank (planning only)
 
 // walker modes (pc_pairs.hip)
 enum { PCW_POCP = 0, PCW_AF = 1, PCW_COUNT = 2, PCW_ENUM = 3, PCW_AAI = 4, PCW_PEQ = 5 };
@@ -80,6 +80,9 @@ int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
 // planning of the alignment batch (pc_plan.hip)
+int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, const int32_t* cls_begin, int ncls, unsigned long long* key, uint32_t* val,
+                        int ntasks, hipStream_t st);
+int pc_launch_task_gather(const PcTask* in, const uint32_t* idx, PcTask* out, int ntasks, hipStream_t st);
 size_t pc_sort_temp_bytes(int64_t n, int bits);
 int pc_sort_pairs(void* temp, size_t temp_bytes, const unsigned long long* key_in, unsigned long long* key_out, const uint32_t* val_in,
                   uint32_t* val_out, int64_t n, int bits, hipStream_t st);

@@ -117,7 +117,7 @@ __global__ void k_task_fill(PcDev d, const uint32_t* __restrict__ start_q, const
     uint32_t to = task_off_q[q];
     const int gene = d.q_gene[q];
     for (uint32_t r = b; r < e; r += per) {
-        PcTask t; t.gene = gene; t.begin = (int32_t)r; t.end = (int32_t)min(e, r + per); t.pad = 0;
+        PcTask t; t.gene = gene; t.begin = (int32_t)r; t.end = (int32_t)min(e, r + per); t.pad = q;
         tasks[to++] = t;
     }
 }
@@ -125,5 +125,36 @@ int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t*
                         PcTask* tasks, int U, hipStream_t st) {
     if (U <= 0) return PC_OK;
     hipLaunchKernelGGL(k_task_fill, dim3((U + 255) / 256), dim3(256), 0, st, d, start_q, end_q, task_rows, task_off_q, tasks, U);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+
+// Longest tasks first inside every launch: a launch's workgroups are dispatched in task order, and a launch that ends
+// on its short tasks drains quickly (the next launch of its hardware queue cannot start before the last workgroup
+// has finished).  key = launch class (position in class order) << 32 | ~(rows * column length); sorted with the same
+// radix sort, the class ranges of the task list do not move.
+__global__ void k_task_keys(PcDev d, const PcTask* __restrict__ tasks, const int32_t* __restrict__ cls_begin, int ncls,
+                            unsigned long long* __restrict__ key, uint32_t* __restrict__ val, int ntasks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntasks) return;
+    const PcTask t = tasks[i];
+    int lo = 0, hi = ncls - 1;                                           // class of column rank t.pad
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cls_begin[mid] <= t.pad) lo = mid; else hi = mid - 1; }
+    const uint32_t work = (uint32_t)(t.end - t.begin) * (uint32_t)d.gene_len[t.gene];
+    key[i] = ((unsigned long long)lo << 32) | (0xffffffffu - work);
+    val[i] = (uint32_t)i;
+}
+__global__ void k_task_gather(const PcTask* __restrict__ in, const uint32_t* __restrict__ idx, PcTask* __restrict__ out, int ntasks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntasks) out[i] = in[idx[i]];
+}
+int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, const int32_t* cls_begin, int ncls, unsigned long long* key, uint32_t* val,
+                        int ntasks, hipStream_t st) {
+    if (ntasks <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_task_keys, dim3((ntasks + 255) / 256), dim3(256), 0, st, d, tasks, cls_begin, ncls, key, val, ntasks);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+int pc_launch_task_gather(const PcTask* in, const uint32_t* idx, PcTask* out, int ntasks, hipStream_t st) {
+    if (ntasks <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_task_gather, dim3((ntasks + 255) / 256), dim3(256), 0, st, in, idx, out, ntasks);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
