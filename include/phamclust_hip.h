@@ -102,6 +102,12 @@ int pc_upload(pc_ctx* ctx, const pc_packed* genomes);
  * pc_shard_pairs: pairs owned; pc_shard_stride: max over ranks (equal-count gather size).
  */
 int pc_set_shard(pc_ctx* ctx, int rank, int world);
+
+/* Same contract, cost-balanced deal: one device pass counts the alignment work (DP cells) behind every target genome,
+ * then targets go, heaviest first, to the rank with the least work so far.  Deterministic, so every rank of a job
+ * arrives at the same partition without communicating; use it on all ranks or on none (pc_assemble_dev follows the
+ * deal that is in force).  Worth it when genomes differ in size or in how much they share. */
+int pc_set_shard_balanced(pc_ctx* ctx, int rank, int world);
 int64_t pc_shard_pairs(const pc_ctx* ctx);
 int64_t pc_shard_stride(const pc_ctx* ctx);
 

@@ -81,9 +81,11 @@ struct pc_ctx {
     int rank = 0, world = 1;
     int64_t shard_pairs = 0, shard_stride = 0;
     PcShard shard{};
+    bool balanced = false;                  // cost-balanced deal in force (pc_set_shard_balanced): assembly goes through the tables
+    std::vector<uint64_t> target_cost;      // DP cells per target genome, computed once per upload
     // persistent device arrays
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
-    DevBuf b_gene_q, b_q_gene, b_cls_idx, b_task_rows, b_owned, b_lbase;
+    DevBuf b_gene_q, b_q_gene, b_cls_idx, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
     DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
@@ -124,7 +126,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
-                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase,
+                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_tasks_sorted, &c->b_bucket_row, &c->b_bucket_dest,
@@ -180,7 +182,7 @@ static int apply_shard(pc_ctx* c, int rank, int world) {
         best = std::max(best, tot);
     }
     c->shard_stride = best;
-    c->rank = rank; c->world = world;
+    c->rank = rank; c->world = world; c->balanced = false;
     int rc = upload_vec(c->b_owned, owned); if (rc != PC_OK) return rc;
     rc = upload_vec(c->b_lbase, lbase); if (rc != PC_OK) return rc;
     c->shard.nown = (int32_t)owned.size();
@@ -210,7 +212,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         fprintf(stderr, "pc_upload %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    c->uploaded = false;
+    c->uploaded = false; c->target_cost.clear();
     PC_HIP(hipStreamSynchronize(c->stream));
 
     // ---- host-side indices -------------------------------------------------------
@@ -364,6 +366,60 @@ extern "C" int pc_set_shard(pc_ctx* c, int rank, int world) {
     int rc = set_device(c); if (rc != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(c->stream));
     return apply_shard(c, rank, world);
+}
+// Cost-balanced deal.  The boustrophedon deal balances pair counts; alignment work per target genome also follows its
+// gene count and how much it shares with the genomes before it.  One COUNT walk over all pairs gives the DP cells per
+// target (integer sums: identical on every rank), then targets go, heaviest first, to the rank with the least work
+// so far (ties: lowest rank) -- the same static, host-decided partition on every rank, no communication.
+extern "C" int pc_set_shard_balanced(pc_ctx* c, int rank, int world) {
+    if (!c || !c->uploaded) { pc_set_error("pc_set_shard_balanced: upload first"); return PC_ERR_STATE; }
+    if (world < 1 || rank < 0 || rank >= world) { pc_set_error("pc_set_shard_balanced: rank %d of %d", rank, world); return PC_ERR_ARG; }
+    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_HIP(hipStreamSynchronize(c->stream));
+    const int N = c->dev.N;
+    if (c->target_cost.empty()) {
+        if ((rc = apply_shard(c, 0, 1))) return rc;                       // walk every pair
+        if ((rc = c->b_cost.ensure((size_t)N * 8)) || (rc = c->b_totals.ensure(64))) return rc;
+        PC_HIP(hipMemsetAsync(c->b_cost.p, 0, (size_t)N * 8, c->stream));
+        PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, c->stream));
+        PcWalkArgs a; memset(&a, 0, sizeof(a));
+        a.totals = c->b_totals.as<unsigned long long>(); a.cost_t = c->b_cost.as<unsigned long long>(); a.condensed = 1;
+        if (c->dev.G > 0 && (rc = pc_launch_walk(PCW_COUNT, c->dev, c->shard, a, c->stream))) return rc;
+        c->target_cost.resize(N);
+        PC_HIP(hipMemcpyAsync(c->target_cost.data(), c->b_cost.p, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+        PC_HIP(hipStreamSynchronize(c->stream));
+    }
+    // every pair also costs a walk visit and an output value: a floor of 2,000 cell-equivalents per pair keeps the
+    // set metrics and sparse data balanced too
+    std::vector<int> order(N);
+    std::iota(order.begin(), order.end(), 0);
+    auto cost = [&](int t) { return c->target_cost[t] + (uint64_t)t * 2000u; };
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) != cost(y) ? cost(x) > cost(y) : x < y; });
+    std::vector<uint64_t> load(world, 0);
+    std::vector<int32_t> t_rank(std::max(N, 1), 0);
+    for (int t : order) {
+        int best = 0;
+        for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+        t_rank[t] = best; load[best] += cost(t);
+    }
+    std::vector<int64_t> t_lbase(std::max(N, 1), 0), fill(world, 0);
+    std::vector<int32_t> owned; std::vector<int64_t> lbase;
+    for (int t = 0; t < N; ++t) {
+        const int r = t_rank[t];
+        t_lbase[t] = fill[r];
+        if (r == rank) { owned.push_back(t); lbase.push_back(fill[r]); }
+        fill[r] += t;
+    }
+    lbase.push_back(fill[rank]);
+    c->shard_pairs = fill[rank];
+    c->shard_stride = *std::max_element(fill.begin(), fill.end());
+    c->rank = rank; c->world = world; c->balanced = true;
+    if ((rc = upload_vec(c->b_owned, owned)) || (rc = upload_vec(c->b_lbase, lbase)) || (rc = upload_vec(c->b_t_rank, t_rank)) ||
+        (rc = upload_vec(c->b_t_lbase, t_lbase))) return rc;
+    c->shard.nown = (int32_t)owned.size();
+    c->shard.owned = c->b_owned.as<int32_t>();
+    c->shard.lbase = c->b_lbase.as<int64_t>();
+    return PC_OK;
 }
 extern "C" int64_t pc_shard_pairs(const pc_ctx* c) { return c && c->uploaded ? c->shard_pairs : -1; }
 extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? c->shard_stride : -1; }
@@ -585,6 +641,9 @@ extern "C" int pc_assemble_dev(pc_ctx* c, const void* gathered_dev, int world, v
     if (!c || !c->uploaded) { pc_set_error("pc_assemble_dev: upload first"); return PC_ERR_STATE; }
     if (world != c->world) { pc_set_error("pc_assemble_dev: world %d != shard world %d", world, c->world); return PC_ERR_ARG; }
     int rc = set_device(c); if (rc != PC_OK) return rc;
+    if (c->balanced)
+        return pc_launch_assemble_table((const double*)gathered_dev, c->shard_stride, c->dev.N, c->b_t_rank.as<int32_t>(), c->b_t_lbase.as<int64_t>(),
+                                        (double*)out_condensed_dev, (hipStream_t)stream);
     return pc_launch_assemble((const double*)gathered_dev, world, c->shard_stride, c->dev.N, (double*)out_condensed_dev,
                               (hipStream_t)stream);
 }

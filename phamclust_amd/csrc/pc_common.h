@@ -51,6 +51,7 @@ struct PcWalkArgs {
     // COUNT
     uint32_t* na;                     // [Lp] alignments per pair
     unsigned long long* totals;       // [0] alignments [1] cells [2] residue bytes (as the reference would run them)
+    unsigned long long* cost_t;       // [N] or NULL: DP cells per target genome (input of the cost-balanced deal)
     // ENUM: alignment slot k of a pair = off[pair] + its position in the reference's loop order
     const uint32_t* off;              // [Lp] exclusive scan of na
     unsigned long long* key;          // [A] (column sequence rank << ubits) | row sequence rank
@@ -94,6 +95,7 @@ int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t*
                         PcTask* tasks, int U, hipStream_t st);
 int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st);
 int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st);
+int pc_launch_assemble_table(const double* gathered, int64_t stride, int N, const int32_t* t_rank, const int64_t* t_lbase, double* out, hipStream_t st);
 int pc_launch_round6_probe(const double* in, double* out, int64_t n, hipStream_t st);
 int pc_launch_unpack_res(const uint2* res, const int32_t* la_plus_lb, int32_t* n_ident, int32_t* n_diag, int64_t n, hipStream_t st);
 

@@ -248,6 +248,7 @@ __device__ __forceinline__ void pc_visit(const PcDev& d, const PcWalkArgs& a, Pc
         p.k += (uint32_t)(ca * cb);
         const unsigned long long la = (unsigned long long)d.ent_len[ea], lb = (unsigned long long)d.ent_len[eb];
         cells += la * lb;
+        p.den += (int64_t)(la * lb);                                                     // per pair, for the cost-balanced deal
         rbytes += la * cb + lb * ca;
     } else if (MODE == PCW_ENUM) {                                                        // sort key per alignment slot (pc_plan.hip)
         for (int ia = 0; ia < ca; ++ia) {
@@ -327,7 +328,11 @@ __global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a)
     if (MODE == PCW_COUNT) {
         unsigned long long nal = 0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) if (ok[m]) { a.na[sh.lbase[kk[m]] + ss[m]] = acc[m].k; nal += acc[m].k; }
+        for (int m = 0; m < 4; ++m) if (ok[m]) {
+            if (a.na) a.na[sh.lbase[kk[m]] + ss[m]] = acc[m].k;
+            if (a.cost_t && acc[m].den) atomicAdd(&a.cost_t[tt[m]], (unsigned long long)acc[m].den);
+            nal += acc[m].k;
+        }
         for (int o = 32; o > 0; o >>= 1) {
             nal += __shfl_down(nal, o); cells += __shfl_down(cells, o); rbytes += __shfl_down(rbytes, o);
         }
@@ -461,6 +466,24 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ gat
     const int64_t lbase = (int64_t)world * (k * (k - 1) / 2) + (int64_t)r * ((k + 1) / 2) + (int64_t)(world - 1 - r) * (k / 2);
     out[(int64_t)s * N - (int64_t)s * (s + 1) / 2 + (t - s - 1)] = gathered[(int64_t)r * stride + lbase + s];
 }
+// Same for an arbitrary deal: t_rank[t] owns target t, whose pairs start at t_lbase[t] inside that rank's shard.
+__global__ __launch_bounds__(256) void k_assemble_table(const double* __restrict__ gathered, int64_t stride, int N,
+                                                         const int32_t* __restrict__ t_rank, const int64_t* __restrict__ t_lbase,
+                                                         double* __restrict__ out) {
+    const int s = blockIdx.y;
+    const int t = s + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    out[(int64_t)s * N - (int64_t)s * (s + 1) / 2 + (t - s - 1)] = gathered[(int64_t)t_rank[t] * stride + t_lbase[t] + s];
+}
+int pc_launch_assemble_table(const double* gathered, int64_t stride, int N, const int32_t* t_rank, const int64_t* t_lbase, double* out, hipStream_t st) {
+    if (N <= 1) return PC_OK;
+    dim3 grid((N + 255) / 256, N - 1);
+    hipLaunchKernelGGL(k_assemble_table, grid, dim3(256), 0, st, gathered, stride, N, t_rank, t_lbase, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_assemble_table launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
 int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st) {
     if (N <= 1) return PC_OK;
     dim3 grid((N + 255) / 256, N - 1);

@@ -64,14 +64,16 @@ def assemble_condensed_host(gathered, n_genomes, world):
     return out
 
 
-def fill_distributed(ctx, metric, as_distance=True, group=None):
+def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True):
     """Sharded fill + the single gather.  ``torch.distributed`` must be initialised (backend
     "nccl" = RCCL) and ``ctx`` must hold the same uploaded genomes on every rank.
-    Returns (condensed f64 CUDA tensor on rank 0 | None elsewhere, stats of this rank)."""
+    ``balanced`` (default): target genomes are dealt by measured alignment work (``pc_set_shard_balanced``: one
+    device pass per upload, identical on every rank); ``False``: the closed-form boustrophedon deal the helpers
+    above describe.  Returns (condensed f64 CUDA tensor on rank 0 | None elsewhere, stats of this rank)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    ctx.set_shard(rank, world)
+    ctx.set_shard(rank, world, balanced=balanced and world > 1)
     stride = ctx.shard_stride()
     device = torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.current_stream().cuda_stream

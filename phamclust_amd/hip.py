@@ -41,7 +41,7 @@ class PcStats(ctypes.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
 
 
-EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard",
+EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe"]
 
@@ -75,6 +75,7 @@ def load():
     L.pc_ctx_destroy.restype = None
     L.pc_upload.argtypes = [vp, ctypes.POINTER(PcPacked)]
     L.pc_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.pc_set_shard_balanced.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.pc_shard_pairs.argtypes = [vp]
     L.pc_shard_pairs.restype = ctypes.c_int64
     L.pc_shard_stride.argtypes = [vp]
@@ -134,7 +135,7 @@ class Context:
                      _ptr(packed.seq_off, _i64p), _ptr(packed.residues, _u8p))
         self._check(self._lib.pc_upload(self._h, ctypes.byref(s)))
         self._packed = packed
-        self._shard = (0, 1)                      # pc_upload resets the shard to "everything"
+        self._shard = (0, 1, False)               # pc_upload resets the shard to "everything"
         return self
 
     @property
@@ -145,10 +146,14 @@ class Context:
     def n_pairs(self):
         return self._packed.n_pairs
 
-    def set_shard(self, rank, world):
-        if getattr(self, "_shard", None) != (int(rank), int(world)):
-            self._check(self._lib.pc_set_shard(self._h, int(rank), int(world)))
-            self._shard = (int(rank), int(world))
+    def set_shard(self, rank, world, balanced=False):
+        """Static shard of the pair list; ``balanced`` deals target genomes by measured alignment work instead of
+        boustrophedon-wise (same on every rank of a job)."""
+        key = (int(rank), int(world), bool(balanced))
+        if getattr(self, "_shard", None) != key:
+            call = self._lib.pc_set_shard_balanced if balanced else self._lib.pc_set_shard
+            self._check(call(self._h, int(rank), int(world)))
+            self._shard = key
 
     def shard_pairs(self):
         return int(self._lib.pc_shard_pairs(self._h))

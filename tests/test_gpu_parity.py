@@ -409,6 +409,46 @@ def test_full_size_peq_properties(gpu_ctx, native_built):
     assert np.array_equal(dist[idx], O.pairs(packed, "peq", lo, hi, as_distance=True))
 
 
+def test_balanced_deal(gpu_ctx, native_built):
+    """pc_set_shard_balanced: every target genome is owned once, the shards assemble to the unsharded matrix for
+    a set metric and an alignment metric, and the alignment work per rank is level (genomes of very different size)."""
+    import torch
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    from phamclust_amd.synth import synth_genomes
+    base = synth_genomes(90, 400, seed=21)
+    genomes = []
+    for i, g in enumerate(base):                            # every third genome keeps only a fifth of its genes
+        h = Genome(g.name)
+        for j, (pham, translations) in enumerate(g):
+            if i % 3 or j % 5 == 0:
+                for t in translations:
+                    h.add(pham, t)
+        genomes.append(h)
+    packed = pack_genomes(genomes)
+    gpu_ctx.upload(packed)
+    stream = torch.cuda.current_stream().cuda_stream
+    for metric in ("jc", "peq"):
+        gpu_ctx.set_shard(0, 1)
+        want = gpu_ctx.fill(metric)
+        for world in (2, 5):
+            parts, pairs, cells = [], 0, []
+            for rank in range(world):
+                gpu_ctx.set_shard(rank, world, balanced=True)
+                buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
+                st = gpu_ctx.fill_shard_dev(metric, True, buf.data_ptr(), stream)
+                parts.append(buf); pairs += gpu_ctx.shard_pairs(); cells.append(st["n_cells"])
+            assert pairs == packed.n_pairs
+            gathered = torch.cat(parts)
+            out = torch.empty(packed.n_pairs, dtype=torch.float64, device="cuda:0")
+            gpu_ctx.assemble_dev(gathered.data_ptr(), world, out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+            if metric == "peq":
+                assert max(cells) <= 1.03 * (sum(cells) / world)
+    gpu_ctx.set_shard(0, 1)
+
+
 def test_fill_distributed_single_rank(gpu_ctx, native_built):
     """The product's multi-GPU entry point with a 1-rank group: shard -> (no gather) -> device assembly."""
     import torch

@@ -12,6 +12,7 @@ from phamclust_amd.synth import synth_packed
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 metric = sys.argv[3] if len(sys.argv) > 3 else "peq"
+balanced = len(sys.argv) > 4 and sys.argv[4] == "balanced"      # pc_set_shard_balanced instead of the boustrophedon deal
 pk = synth_packed(n, 5000)
 ctx = hip.Context(0); ctx.upload(pk)
 stream = torch.cuda.current_stream().cuda_stream
@@ -20,7 +21,7 @@ st = ctx.fill_dev(metric, True, full.data_ptr(), stream); torch.cuda.synchronize
 print(f"unsharded: {st['ms_total']:.1f} ms, {st['n_cells']:.3e} cells", flush=True)
 parts, rows = [], []
 for r in range(world):
-    ctx.set_shard(r, world)
+    ctx.set_shard(r, world, balanced=balanced)
     buf = torch.empty(ctx.shard_stride(), dtype=torch.float64, device="cuda")
     ctx.fill_shard_dev(metric, True, buf.data_ptr(), stream)            # warm
     s = ctx.fill_shard_dev(metric, True, buf.data_ptr(), stream); torch.cuda.synchronize()
