@@ -321,7 +321,14 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     }
     std::vector<int32_t> q_gene(std::max(U, 1), 0), task_rows(std::max(U, 1), PC_TASK_ROWS);
     std::vector<uint32_t> q_of_u(std::max(U, 1), 0), gene_q(std::max(G, 1), 0);
-    for (int u = 0; u < U; ++u) {
+    // ranks inside a class follow sequence length (then first occurrence): the plan's sort then hands every bucket its
+    // rows in length order, so the row streams of a task, dealt round-robin, stay in step and start their alignments
+    // in the same steps (the per-step cost of an alignment start is paid once per wave, not once per segment; measured
+    // gain 0.3 %: rows of one pham are nearly equally long anyway)
+    std::vector<int32_t> u_order(U);
+    std::iota(u_order.begin(), u_order.end(), 0);
+    std::stable_sort(u_order.begin(), u_order.end(), [&](int32_t x, int32_t y) { return gene_len[u_gene[x]] < gene_len[u_gene[y]]; });
+    for (int u : u_order) {
         const int q = (int)cls_pos[u_cls[u]]++;
         const int len = gene_len[u_gene[u]];
         q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];

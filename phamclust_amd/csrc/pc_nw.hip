@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 // ---------------------------------------------------------------------------------
 // Systolic kernel (the production path): wavefront-level anti-diagonal sweep.
 //
-// One workgroup (4 waves) per task = one column gene + up to 256 of its row sequences; the
+// One workgroup (4 waves) per task = one column gene + up to PC_TASK_ROWS of its row sequences; the
 // waves share the column gene's substitution profile in LDS (the profile is 24*lb bytes, so
 // sharing it is what keeps 4 waves per SIMD resident for long genes) and otherwise run
 // independently (one barrier, after the profile is built).  Within a wave the column
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     const bool is_head = in_seg && k == 0;
     const int k_out = (lb - 1) / W, c_out = (lb - 1) - k_out * W;
     const bool is_out = in_seg && k == k_out;
-    const int R = tk.end - tk.begin;                // rows (alignments) of this workgroup task, <= 256
+    const int R = tk.end - tk.begin;                // rows (alignments) of this workgroup task, <= PC_TASK_ROWS
     // wave-local row lr <-> task row (lr / nseg) * NS + wv * nseg + lr % nseg  (monotone in lr)
     auto task_row = [&](int lr) { return (lr / nseg) * NS + wv * nseg + (lr % nseg); };
 
