@@ -93,6 +93,10 @@ class _Run:
         return path
 
     def banner(self, number, title):
+        now = time.perf_counter()
+        if getattr(self, "_stage_t0", None) is not None:
+            log.info(f"    ({now - self._stage_t0:.1f} s)")          # wall time of the stage that just ended
+        self._stage_t0 = now
         log.info(f"--- {number}: {title} ---")
 
     # 1
