@@ -60,7 +60,7 @@ def build_synth(force=False, verbose=False):
 def build_pack(force=False, verbose=False):
     src = os.path.join(CSRC, "pc_pack.c")
     if force or _stale(PACK_LIB, [src]):
-        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-o", PACK_LIB, src]
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-o", PACK_LIB, src, "-lm"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

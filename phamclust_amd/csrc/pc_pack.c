@@ -182,3 +182,68 @@ pcp_data* pcp_load_tsv(const char* path) {
     free(genes); free(gnames); free(pnames); free(gorder); free(grank); free(porder); free(prank);
     return d;
 }
+
+/* ---------------------------------------------------------------------------------------
+ * Matrix text I/O (reference matrix.py:500-670 writes every value with "%.6f"): formatting
+ * and parsing of one row at a time, so that N = 10,000 matrices (5*10^7 values, 450 MB of
+ * text) do not go through a Python format call per value.  Byte-compatible with "%.6f".
+ * ------------------------------------------------------------------------------------- */
+#include <math.h>
+
+/* "%.6f" of one double.  Fast path: |x| < 1e9 and x*1e6 is within 0.49 of an integer k that the product cannot
+ * mis-round (the product's rounding error is ~1e-10 relative) -> print k as d.dddddd; anything else goes
+ * through snprintf, so the bytes are always those of "%.6f". */
+static char* fmt6(double x, char* p) {
+    if (x == x && fabs(x) < 1e9) {
+        const double y = fabs(x) * 1e6, k = nearbyint(y);
+        if (fabs(y - k) < 0.49) {
+            unsigned long long v = (unsigned long long)k;
+            char tmp[24]; int n = 0;
+            for (int i = 0; i < 6; ++i) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
+            tmp[n++] = '.';
+            do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+            if (signbit(x)) *p++ = '-';
+            while (n) *p++ = tmp[--n];
+            return p;
+        }
+    }
+    return p + snprintf(p, 400, "%.6f", x);
+}
+
+/* values joined by tabs, terminated by '\n'; returns bytes written (out must hold 24 bytes per value + 400) */
+int64_t pcp_format_row(const double* v, int64_t n, char* out) {
+    char* p = out;
+    for (int64_t i = 0; i < n; ++i) { if (i) *p++ = '\t'; p = fmt6(v[i], p); }
+    *p++ = '\n';
+    return (int64_t)(p - out);
+}
+
+/* adjacency lines "source<TAB>target<TAB>value\n" for targets j0..n-1 of one source row (reference matrix.py
+ * matrix_to_adjacency); names: concatenated UTF-8, name_off[n+1].  skip_zero drops values equal to 0. */
+int64_t pcp_format_adjacency(const char* src, int64_t src_len, const char* names, const int64_t* name_off, const double* row,
+                             int64_t j0, int64_t n, int skip_zero, char* out) {
+    char* p = out;
+    for (int64_t j = j0; j < n; ++j) {
+        if (skip_zero && row[j] == 0.0) continue;
+        memcpy(p, src, (size_t)src_len); p += src_len; *p++ = '\t';
+        const int64_t len = name_off[j + 1] - name_off[j];
+        memcpy(p, names + name_off[j], (size_t)len); p += len; *p++ = '\t';
+        p = fmt6(row[j], p); *p++ = '\n';
+    }
+    return (int64_t)(p - out);
+}
+
+/* tab-separated decimal fields of one line -> doubles (strtod: same values as Python's float()); returns the
+ * count parsed, or -(position+1) of the first field that is not a number */
+int64_t pcp_parse_row(const char* text, int64_t len, double* out, int64_t cap) {
+    int64_t n = 0;
+    const char* p = text; const char* end = text + len;
+    while (p < end && n < cap) {
+        char* q;
+        out[n] = strtod(p, &q);
+        if (q == p) return -(int64_t)(p - text) - 1;
+        ++n; p = q;
+        if (p < end && *p == '\t') ++p; else break;
+    }
+    return n;
+}

@@ -362,12 +362,56 @@ def matrix_from_adjacency(filepath):
     return matrix
 
 
+_TEXT_LIB = None
+
+
+def _text_lib():
+    """csrc/libpc_pack.so's row formatter / parser ("%.6f", byte for byte), or None when it is not built: the text
+    I/O then runs in Python (same bytes, ~100x slower at N = 10,000)."""
+    global _TEXT_LIB
+    if _TEXT_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpc_pack.so")
+        try:
+            lib = ctypes.CDLL(path)
+            lib.pcp_format_row.restype = ctypes.c_int64
+            lib.pcp_format_row.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
+            lib.pcp_format_adjacency.restype = ctypes.c_int64
+            lib.pcp_format_adjacency.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p]
+            lib.pcp_parse_row.restype = ctypes.c_int64
+            lib.pcp_parse_row.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+            _TEXT_LIB = lib
+        except (OSError, AttributeError):
+            _TEXT_LIB = False
+    return _TEXT_LIB or None
+
+
 def matrix_to_adjacency(matrix, filepath, skip_zero=False):
-    with open(filepath, "w") as handle:
-        for source, target, weight in matrix:
-            if skip_zero and not weight:
-                continue
-            handle.write(f"{source}\t{target}\t{weight:.6f}\n")
+    lib = _text_lib() if isinstance(matrix, SymMatrix) else None
+    data = matrix._ordered() if lib else None
+    if lib is None or np.isnan(data).any():                 # unset cells: the reference's formatting error surfaces below
+        with open(filepath, "w") as handle:
+            for source, target, weight in matrix:
+                if skip_zero and not weight:
+                    continue
+                handle.write(f"{source}\t{target}\t{weight:.6f}\n")
+        return filepath
+    import ctypes
+    names = [name.encode() for name in matrix.nodes]
+    blob = b"".join(names)
+    offsets = np.zeros(len(names) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in names], out=offsets[1:])
+    n = len(names)
+    width = (max((len(x) for x in names), default=0)) * 2 + 32
+    buf = ctypes.create_string_buffer(n * width + 512)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    with open(filepath, "wb") as handle:
+        for i, source in enumerate(names):
+            size = lib.pcp_format_adjacency(source, len(source), blob, offsets.ctypes.data, data[i].ctypes.data, i, n,
+                                            1 if skip_zero else 0, buf)
+            handle.write(buf.raw[:size] if size < 65536 else memoryview(buf)[:size])
     return filepath
 
 
@@ -379,12 +423,32 @@ def read_squareform(filepath):
             yield fields[0], [float(x) for x in fields[1:]]
 
 
+def _read_rows(filepath):
+    """(name, ndarray row) per line: the C parser when csrc/libpc_pack.so is there, else read_squareform."""
+    lib = _text_lib()
+    if lib is None:
+        for name, row in read_squareform(filepath):
+            yield name, np.asarray(row, dtype=np.float64)
+        return
+    with open(filepath, "rb") as handle:
+        next(handle)
+        for line in handle:
+            line = line.rstrip()
+            name, tab, rest = line.partition(b"\t")
+            cap = rest.count(b"\t") + 1 if tab else 0
+            row = np.empty(cap, dtype=np.float64)
+            got = lib.pcp_parse_row(rest, len(rest), row.ctypes.data, cap) if cap else 0
+            if got != cap:
+                raise ValueError(f"{filepath}: could not parse the row of {name.decode()!r}")
+            yield name.decode(), row
+
+
 def matrix_from_squareform(filepath):
     names, rows, diagonal = [], [], set()
-    for i, (target, row) in enumerate(read_squareform(filepath)):
+    for i, (target, row) in enumerate(_read_rows(filepath)):
         names.append(target)
         rows.append(row)
-        diagonal.add(row[i])
+        diagonal.add(float(row[i]))
     matrix = SymMatrix(names, is_distance=_diagonal_kind(diagonal, len(diagonal)))
     n = len(names)
     data = matrix._data
@@ -400,14 +464,31 @@ def matrix_from_squareform(filepath):
 
 
 def matrix_to_squareform(matrix, filepath, lower_triangle=False):
-    with open(filepath, "w") as handle:
-        header = f"{len(matrix)}"
+    lib = _text_lib() if isinstance(matrix, SymMatrix) else None
+    data = matrix._ordered() if lib else None
+    if lib is None or np.isnan(data).any():
+        with open(filepath, "w") as handle:
+            header = f"{len(matrix)}"
+            if not lower_triangle:
+                header += "\t" + "\t".join(matrix.nodes)
+            handle.write(f"{header}\n")
+            for i, (source, row) in enumerate(matrix.iterrows()):
+                cells = row[:i + 1] if lower_triangle else row
+                handle.write(f"{source}\t" + "\t".join([f"{x:.6f}" for x in cells]) + "\n")
+        return filepath
+    import ctypes
+    n = len(matrix)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    buf = ctypes.create_string_buffer(n * 24 + 512)
+    with open(filepath, "wb") as handle:
+        header = f"{n}"
         if not lower_triangle:
             header += "\t" + "\t".join(matrix.nodes)
-        handle.write(f"{header}\n")
-        for i, (source, row) in enumerate(matrix.iterrows()):
-            cells = row[:i + 1] if lower_triangle else row
-            handle.write(f"{source}\t" + "\t".join([f"{x:.6f}" for x in cells]) + "\n")
+        handle.write(f"{header}\n".encode())
+        for i, source in enumerate(matrix.nodes):
+            size = lib.pcp_format_row(data[i].ctypes.data, i + 1 if lower_triangle else n, buf)
+            handle.write(source.encode() + b"\t")
+            handle.write(memoryview(buf)[:size])
     return filepath
 
 

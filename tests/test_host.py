@@ -275,3 +275,43 @@ def test_graft_entry_build(native_built):
     sys.path.insert(0, REPO)
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_text_io_c_path_is_byte_identical(native_built, tmp_path):
+    """The C row formatter / parser behind matrix_to_squareform, matrix_to_adjacency and read_squareform produce the
+    bytes (and values) of the Python "%.6f" path, on rounded values and on arbitrary doubles (ties, tiny, 1.0)."""
+    import ctypes
+    from phamclust_amd import matrix as M
+    lib = M._text_lib()
+    assert lib is not None
+    rng = np.random.default_rng(5)
+    special = np.array([0.0, 1.0, 0.5, 1e-7, 4.9999999e-7, 5e-7, 5.0000001e-7, 0.9999995, 0.99999949, 0.1234565, 0.1234575,
+                        2.5e-6, 3.5e-6, 123456.7890125, -0.0, -1e-9, -0.25, 1e8, 0.000001, 0.999999])
+    values = np.concatenate([special, rng.random(5000), np.round(rng.random(5000), 6), rng.random(200) * 1e-6])
+    buf = ctypes.create_string_buffer(values.size * 24 + 512)
+    size = lib.pcp_format_row(values.ctypes.data, values.size, buf)
+    assert buf.raw[:size] == ("\t".join(f"{x:.6f}" for x in values.tolist()) + "\n").encode()
+    back = np.empty(values.size)
+    assert lib.pcp_parse_row(buf.raw[:size - 1], size - 1, back.ctypes.data, values.size) == values.size
+    assert back.tolist() == [float(f"{x:.6f}") for x in values.tolist()]
+    # whole files, both code paths
+    n = 37
+    names = [f"g{'x' * (i % 5)}{i:03d}" for i in range(n)]
+    m = M.SymMatrix(names, is_distance=True)
+    cond = np.round(rng.random(n * (n - 1) // 2), 6)
+    cond[::7] = 0.0
+    m = M.SymMatrix.from_condensed(names, cond, is_distance=True)
+    outputs = {}
+    for label, forced in (("c", lib), ("py", False)):
+        M._TEXT_LIB = forced
+        try:
+            paths = [M.matrix_to_squareform(m, tmp_path / f"{label}_sq.tsv"), M.matrix_to_squareform(m, tmp_path / f"{label}_lt.tsv", lower_triangle=True),
+                     M.matrix_to_adjacency(m, tmp_path / f"{label}_adj.tsv"), M.matrix_to_adjacency(m, tmp_path / f"{label}_adj0.tsv", skip_zero=True)]
+            outputs[label] = [open(p, "rb").read() for p in paths]
+            rows = [(name, row.tolist()) for name, row in M._read_rows(paths[1])]
+            assert [r[0] for r in rows] == names and all(len(r[1]) == i + 1 for i, r in enumerate(rows))
+            back = M.matrix_from_squareform(paths[1])
+            outputs[label] += [rows, back.nodes, back.to_ndarray().tolist() if hasattr(back.to_ndarray(), "tolist") else back.to_ndarray()]
+        finally:
+            M._TEXT_LIB = lib
+    assert outputs["c"] == outputs["py"]
