@@ -449,6 +449,32 @@ def test_balanced_deal(gpu_ctx, native_built):
     gpu_ctx.set_shard(0, 1)
 
 
+@pytest.mark.parametrize("balanced", [False, True])
+def test_more_ranks_than_genomes(gpu_ctx, native_built, balanced):
+    """3 genomes dealt to 8 ranks: most ranks own nothing, their fills are no-ops, the assembly is still complete."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(3, 60, seed=4)
+    gpu_ctx.upload(packed)
+    stream = torch.cuda.current_stream().cuda_stream
+    for metric in ("gcs", "pocp", "peq"):
+        gpu_ctx.set_shard(0, 1)
+        want = gpu_ctx.fill(metric)
+        parts, pairs = [], 0
+        for rank in range(8):
+            gpu_ctx.set_shard(rank, 8, balanced=balanced)
+            buf = torch.full((max(gpu_ctx.shard_stride(), 1),), -1.0, dtype=torch.float64, device="cuda:0")
+            gpu_ctx.fill_shard_dev(metric, True, buf.data_ptr(), stream)
+            parts.append(buf[:gpu_ctx.shard_stride()]); pairs += gpu_ctx.shard_pairs()
+        assert pairs == 3
+        gathered = torch.cat(parts)
+        out = torch.empty(3, dtype=torch.float64, device="cuda:0")
+        gpu_ctx.assemble_dev(gathered.data_ptr(), 8, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    gpu_ctx.set_shard(0, 1)
+
+
 def test_fill_distributed_single_rank(gpu_ctx, native_built):
     """The product's multi-GPU entry point with a 1-rank group: shard -> (no gather) -> device assembly."""
     import torch
