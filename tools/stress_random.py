@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Randomised stress of all six metrics against the oracle on many small collections (paralogs, byte-identical
+sequences, odd residues, lengths up to 1,500): `python tools/stress_random.py SEED TRIALS`.  r01: seed 4242, 1,500
+collections, 9,000 fills, 0 mismatches."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as O
+from phamclust_amd import hip
+from phamclust_amd.genome import Genome
+from phamclust_amd.pack import pack_genomes
+ctx = hip.Context(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 777)
+letters = np.array(list("ACDEFGHIKLMNPQRSTVWY" * 3 + "BZX*Uacdw-"))
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
+    n_genomes, n_phams = int(rng.integers(2, 14)), int(rng.integers(1, 9))
+    maxlen = int(rng.choice([12, 90, 400, 1500]))
+    pool = ["".join(letters[rng.integers(0, letters.size, int(rng.integers(1, maxlen + 1)))]) for _ in range(int(rng.integers(1, 10)))]
+    genomes = []
+    for g in range(n_genomes):
+        genome = Genome(f"g{g:02d}")
+        for p in rng.permutation(n_phams)[:int(rng.integers(1, n_phams + 1))]:
+            for _ in range(int(rng.integers(1, 5)) if rng.random() < 0.3 else 1):
+                seq = pool[int(rng.integers(0, len(pool)))]
+                if rng.random() < 0.5:
+                    cut = int(rng.integers(0, len(seq)))
+                    seq = seq[:cut] + "W" + seq[cut + 1:] if rng.random() < 0.5 else seq[:max(1, cut)]
+                genome.add(f"pham{p}", seq)
+        genomes.append(genome)
+    packed = pack_genomes(genomes)
+    ctx.upload(packed)
+    for metric in ("gcs", "jc", "pocp", "af", "aai", "peq"):
+        got = ctx.fill(metric, as_distance=bool(trial & 1))
+        want = O.fill(packed, metric, as_distance=bool(trial & 1))
+        if not np.array_equal(got, want):
+            bad += 1; print("MISMATCH", trial, metric, flush=True)
+    if trial % 100 == 99: print("trial", trial + 1, "mismatches", bad, flush=True)
+print("done, mismatches", bad)
+sys.exit(1 if bad else 0)
