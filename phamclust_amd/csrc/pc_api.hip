@@ -74,9 +74,9 @@ struct pc_ctx {
     std::vector<int32_t> h_gene_len;
     int max_gene_len = 0, min_gene_len = 0, max_nph = 0;
     // kernel-variant classes over column genes
-    std::vector<int> cls_variant;           // per class: variant id, -1 = general kernel
-    std::vector<int32_t> cls_begin;         // [ncls+1] positions in class order
-    std::vector<int> cls_max_lb;
+    int ncls_all = 0;                       // launch classes: variant * 4 + lanes-per-segment bucket, last = general kernel
+    std::vector<int32_t> cls_max_lb;        // [ncls_all] longest column sequence that can land in the class (LDS size of its launch)
+    PcTaskPlan task_plan{};
     // shard
     int rank = 0, world = 1;
     int64_t shard_pairs = 0, shard_stride = 0;
@@ -85,7 +85,7 @@ struct pc_ctx {
     std::vector<uint64_t> target_cost;      // DP cells per target genome, computed once per upload
     // persistent device arrays
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
-    DevBuf b_gene_q, b_q_gene, b_cls_idx, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
+    DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
     DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
@@ -126,7 +126,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
-                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_cls_idx, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
+                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_tasks_sorted, &c->b_bucket_row, &c->b_bucket_dest,
@@ -295,32 +295,44 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     lap("distinct sequences");
     const int nvar = pc_nw_num_variants();
     const int ncls_all = nvar * 4 + 1;                 // last class: general kernel
-    std::vector<int> u_cls(U), len_cls(maxlen + 1, -1), len_rows(maxlen + 1, 0);     // per length: class, rows per task
+    std::vector<int> u_cls(U), len_cls(maxlen + 1, -1), len_rows(maxlen + 1, 0), len_var(maxlen + 1, -1);   // per length: class, rows per task, variant
     std::vector<int64_t> cls_count(ncls_all, 0);
-    std::vector<int> cls_maxlb(ncls_all, 0);
     for (int u = 0; u < U; ++u) {
         const int len = gene_len[u_gene[u]];
         if (len_cls[len] < 0) {
             const int variant = pc_nw_choose_variant(len);
+            len_var[len] = variant;
             len_cls[len] = pc_class_of(len, variant);
             len_rows[len] = pc_nw_task_rows(len, variant);
         }
-        const int cls = len_cls[len];
-        u_cls[u] = cls; ++cls_count[cls]; cls_maxlb[cls] = std::max(cls_maxlb[cls], len);
+        u_cls[u] = len_cls[len]; ++cls_count[len_cls[len]];
     }
-    c->cls_variant.clear(); c->cls_begin.clear(); c->cls_max_lb.clear();
+    if (ncls_all > 250) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // class ids travel in a byte, 255 = none
+    c->ncls_all = ncls_all;
     std::vector<int64_t> cls_pos(ncls_all, 0);
-    {
-        int64_t run = 0;
-        for (int cls = 0; cls < ncls_all; ++cls) {
-            cls_pos[cls] = run;
-            if (cls_count[cls]) { c->cls_variant.push_back(cls == ncls_all - 1 ? -1 : cls / 4); c->cls_begin.push_back((int32_t)run); c->cls_max_lb.push_back(cls_maxlb[cls]); }
-            run += cls_count[cls];
-        }
-        c->cls_begin.push_back((int32_t)run);
-    }
+    { int64_t run = 0; for (int cls = 0; cls < ncls_all; ++cls) { cls_pos[cls] = run; run += cls_count[cls]; } }
     std::vector<int32_t> q_gene(std::max(U, 1), 0), task_rows(std::max(U, 1), PC_TASK_ROWS);
     std::vector<uint32_t> q_of_u(std::max(U, 1), 0), gene_q(std::max(G, 1), 0);
+    std::vector<uint8_t> q_class(std::max(U, 1), 0), q_nseg(std::max(U, 1), 1), rem_class((size_t)std::max(U, 1) * 16, 255);
+    // per length: segments per wave of the main variant and where a remainder of r rows goes (class id, 255 = stays)
+    std::vector<uint8_t> len_nseg(maxlen + 1, 1), len_rem((size_t)(maxlen + 1) * 16, 255);
+    c->cls_max_lb.assign(ncls_all, 0);
+    for (int len = 0; len <= maxlen; ++len) if (len_cls[len] >= 0) c->cls_max_lb[len_cls[len]] = std::max(c->cls_max_lb[len_cls[len]], len);
+    for (int len = 1; len <= maxlen; ++len) {
+        const int v = len_var[len];
+        if (len_cls[len] < 0 || v < 0) continue;
+        const int Wv = pc_nw_variant_w(v), Gv = (len + Wv - 1) / Wv;
+        const int nseg = std::min(64 / Gv, 16);
+        len_nseg[len] = (uint8_t)nseg;
+        for (int r = 1; r < nseg; ++r) {
+            const int vr = pc_nw_choose_remainder(len, r, v);
+            if (vr >= 0) {
+                const int cr = pc_class_of(len, vr);
+                len_rem[(size_t)len * 16 + r] = (uint8_t)cr;
+                c->cls_max_lb[cr] = std::max(c->cls_max_lb[cr], len);
+            }
+        }
+    }
     // ranks inside a class follow sequence length (then first occurrence): the plan's sort then hands every bucket its
     // rows in length order, so the row streams of a task, dealt round-robin, stay in step and start their alignments
     // in the same steps (the per-step cost of an alignment start is paid once per wave, not once per segment; measured
@@ -333,11 +345,12 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         const int len = gene_len[u_gene[u]];
         q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];
         task_rows[q] = len_rows[len];
+        q_class[q] = (uint8_t)u_cls[u]; q_nseg[q] = len_nseg[len];
+        memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16);
     }
     for (int k = 0; k < G; ++k) gene_q[k] = q_of_u[uid[k]];
     int ubits = 1;
     while ((1LL << ubits) < U) ++ubits;
-    if (c->cls_begin.size() > 900) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // h_plan: 1000 u32, then the totals
 
     lap("launch classes");
     // ---- device copies ---------------------------------------------------------------
@@ -347,8 +360,11 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
         (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_vec(c->b_codes, codes)) || (rc = upload_vec(c->b_nph, nph)) ||
         (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
-        (rc = upload_vec(c->b_cls_idx, c->cls_begin)))
+        (rc = upload_vec(c->b_q_class, q_class)) || (rc = upload_vec(c->b_q_nseg, q_nseg)) || (rc = upload_vec(c->b_rem_class, rem_class)) ||
+        (rc = c->b_cls_begin.ensure((ncls_all + 1) * 4)))
         return rc;
+    c->task_plan.task_rows = c->b_task_rows.as<int32_t>(); c->task_plan.q_class = c->b_q_class.as<uint8_t>();
+    c->task_plan.q_nseg = c->b_q_nseg.as<uint8_t>(); c->task_plan.rem_class = c->b_rem_class.as<uint8_t>();
     PcDev& d = c->dev;
     d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)ent_cnt.size();
     d.U = U; d.ubits = ubits; d.gene_q = c->b_gene_q.as<uint32_t>(); d.q_gene = c->b_q_gene.as<int32_t>();
@@ -435,8 +451,10 @@ extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? 
 // Step 5 of the plan: launch the alignment kernels for every class that has tasks.  Classes are
 // independent (disjoint result slots), so their launches are spread over the caller's stream and
 // seven auxiliary streams: the drain of one class overlaps the next one's start.
-static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[ncls+1]*/, hipStream_t st, pc_stats* stats, int ppos) {
-    const int ncls = (int)c->cls_variant.size();
+static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[ncls_all+1]*/, const int32_t* cls_max_lb,
+                             hipStream_t st, pc_stats* stats, int ppos) {
+    const int ncls = c->ncls_all;
+    auto variant_of = [&](int cls) { return cls == ncls - 1 ? -1 : cls / 4; };
     std::vector<int> order;
     for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
     // longest tasks first (a task's duration grows with its column gene's length): the tail of the fill is then made
@@ -447,13 +465,13 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
             const uint32_t nx = task_begin[x + 1] - task_begin[x], ny = task_begin[y + 1] - task_begin[y];
             return nx != ny ? nx > ny : x < y;
         }
-        return c->cls_max_lb[x] != c->cls_max_lb[y] ? c->cls_max_lb[x] > c->cls_max_lb[y] : x < y;
+        return cls_max_lb[x] != cls_max_lb[y] ? cls_max_lb[x] > cls_max_lb[y] : x < y;
     });
     if (order.empty()) return PC_OK;
     // scratch of the general kernel: sized once for the longest column gene that will use it (never re-allocated
     // between launches)
     size_t sbytes = 0;
-    for (int i : order) if (ppos || c->cls_variant[i] < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(c->cls_max_lb[i]));
+    for (int i : order) if (ppos || variant_of(i) < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(cls_max_lb[i]));
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     constexpr int kAux = pc_ctx::kAux;
     PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
@@ -461,12 +479,12 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     int slot = 0;
     for (int i : order) {
         const int nt = (int)(task_begin[i + 1] - task_begin[i]);
-        const int variant = ppos ? -1 : c->cls_variant[i];        // percent-positives: general kernel (rare, no CLI route)
+        const int variant = ppos ? -1 : variant_of(i);            // percent-positives: general kernel (rare, no CLI route)
         // launches that use the one scratch slab stay in order on the caller's stream
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
                               nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
-                              variant < 0 ? c->b_scratch.cap : 0, c->cls_max_lb[i], ppos, ls);
+                              variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) % c->n_streams;
@@ -516,7 +534,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
             pc_set_error("fill: an empty translation cannot be aligned (aai/peq); the reference fails on it too"); return PC_ERR_DATA;
         }
         const int U = d.U;
-        const int ncls = (int)c->cls_variant.size();
+        const int ncls = c->ncls_all;
         const int64_t tmp_fixed = std::max<int64_t>(Lp + 1, U + 1);
         if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_start_q.ensure((U + 1) * 4)) ||
             (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) || (rc = c->b_task_off_q.ensure((U + 1) * 4)) ||
@@ -560,45 +578,44 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
             if ((rc = pc_launch_unique(d, c->b_key1.as<unsigned long long>(), c->b_val1.as<uint32_t>(), c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(),
                                        c->b_alias.as<uint32_t>(), c->b_bucket_row.as<int32_t>(), c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(),
                                        c->b_totals.as<unsigned long long>(), An, st))) return rc;
-            // 5 workgroup tasks per column sequence; second read-back: task range per launch class, distinct totals
-            if ((rc = pc_launch_task_count(c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->b_task_rows.as<int32_t>(), c->b_ntask_q.as<uint32_t>(), U, st))) return rc;
+            // 5 workgroup tasks per column sequence (a bucket's left-over rows may go to a narrower variant); second
+            //   read-back: number of tasks, distinct totals
+            if ((rc = pc_launch_task_count(c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->task_plan, c->b_ntask_q.as<uint32_t>(), U, st))) return rc;
             if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), U + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-            if ((rc = pc_launch_gather_u32(c->b_task_off_q.as<uint32_t>(), c->b_cls_idx.as<int32_t>(), c->b_plan.as<uint32_t>(), ncls + 1, st))) return rc;
-            PC_HIP(hipMemcpyAsync(c->h_plan, c->b_plan.p, (ncls + 1) * 4, hipMemcpyDeviceToHost, st));
+            PC_HIP(hipMemcpyAsync(c->h_plan, c->b_task_off_q.as<uint32_t>() + U, 4, hipMemcpyDeviceToHost, st));
             PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 40, hipMemcpyDeviceToHost, st));
             PC_HIP(hipStreamSynchronize(st));
-            const uint32_t ntasks = c->h_plan[ncls];
+            const uint32_t ntasks = c->h_plan[0];
             local.n_tasks = ntasks; local.n_distinct_alignments = (int64_t)h_tot[3]; local.n_distinct_cells = (int64_t)h_tot[4];
-            if ((rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask)))) return rc;
-            if ((rc = pc_launch_task_fill(d, c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->b_task_rows.as<int32_t>(),
+            int cbits = 1; while ((1 << cbits) < ncls) ++cbits;
+            const size_t tb_bytes = pc_sort_temp_bytes((int64_t)std::max<uint32_t>(ntasks, 1), 32 + cbits);
+            if ((rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))) || (rc = c->b_tasks_sorted.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))) ||
+                (rc = c->b_key0.ensure((size_t)ntasks * 8)) || (rc = c->b_key1.ensure((size_t)ntasks * 8)) || (rc = c->b_val0.ensure((size_t)ntasks * 4)) ||
+                (rc = c->b_val1.ensure((size_t)ntasks * 4)) || (rc = c->b_sort_tmp.ensure(std::max<size_t>(tb_bytes, 16))))
+                return rc;
+            if ((rc = pc_launch_task_fill(d, c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->task_plan,
                                           c->b_task_off_q.as<uint32_t>(), c->b_tasks.as<PcTask>(), U, st))) return rc;
-            // longest tasks first inside every launch class (same radix sort; key/value buffers of the alignment sort are free again)
-            static const bool sort_tasks = !(getenv("PC_TASK_ORDER") && !strcmp(getenv("PC_TASK_ORDER"), "plain"));
-            const PcTask* task_list = c->b_tasks.as<PcTask>();
-            if (sort_tasks && ntasks > 1) {
-                int cbits = 1; while ((1 << cbits) < ncls) ++cbits;
-                const size_t tb_bytes = pc_sort_temp_bytes((int64_t)ntasks, 32 + cbits);
-                if ((rc = c->b_tasks_sorted.ensure((size_t)ntasks * sizeof(PcTask))) || (rc = c->b_key0.ensure((size_t)ntasks * 8)) ||
-                    (rc = c->b_key1.ensure((size_t)ntasks * 8)) || (rc = c->b_val0.ensure((size_t)ntasks * 4)) || (rc = c->b_val1.ensure((size_t)ntasks * 4)) ||
-                    (rc = c->b_sort_tmp.ensure(std::max<size_t>(tb_bytes, 16))))
-                    return rc;
-                if ((rc = pc_launch_task_keys(d, c->b_tasks.as<PcTask>(), c->b_cls_idx.as<int32_t>(), ncls, c->b_key0.as<unsigned long long>(),
-                                              c->b_val0.as<uint32_t>(), (int)ntasks, st))) return rc;
-                if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
-                                        c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), (int64_t)ntasks, 32 + cbits, st))) return rc;
-                if ((rc = pc_launch_task_gather(c->b_tasks.as<PcTask>(), c->b_val1.as<uint32_t>(), c->b_tasks_sorted.as<PcTask>(), (int)ntasks, st))) return rc;
-                task_list = c->b_tasks_sorted.as<PcTask>();
-            }
+            // 6 the task list sorted by (launch class, longest first) with the same radix sort (the key/value buffers of the
+            //   alignment sort are free again); third read-back: task range and longest column per launch class
+            if ((rc = pc_launch_task_keys(d, c->b_tasks.as<PcTask>(), c->b_key0.as<unsigned long long>(),
+                                          c->b_val0.as<uint32_t>(), (int)ntasks, st))) return rc;
+            if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
+                                    c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), (int64_t)ntasks, 32 + cbits, st))) return rc;
+            if ((rc = pc_launch_task_gather(c->b_tasks.as<PcTask>(), c->b_val1.as<uint32_t>(), c->b_tasks_sorted.as<PcTask>(), (int)ntasks, st))) return rc;
+            if ((rc = pc_launch_class_bounds(c->b_key1.as<unsigned long long>(), (int)ntasks, ncls, c->b_cls_begin.as<uint32_t>(), st))) return rc;
+            PC_HIP(hipMemcpyAsync(c->h_plan, c->b_cls_begin.p, (size_t)(ncls + 1) * 4, hipMemcpyDeviceToHost, st));
+            PC_HIP(hipStreamSynchronize(st));
+            const PcTask* task_list = c->b_tasks_sorted.as<PcTask>();
             PC_HIP(hipEventRecord(c->ev[1], st));
-            // 6 K4: one result per distinct alignment, addressed by its position in the sorted list
+            // 7 K4: one result per distinct alignment, addressed by its position in the sorted list
             std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
-            if ((rc = run_align_classes(c, task_list, tb.data(), st, &local, ppos))) return rc;
+            if ((rc = run_align_classes(c, task_list, tb.data(), c->cls_max_lb.data(), st, &local, ppos))) return rc;
             PC_HIP(hipEventRecord(c->ev[2], st));
         } else {
             PC_HIP(hipEventRecord(c->ev[1], st));
             PC_HIP(hipEventRecord(c->ev[2], st));
         }
-        // 7 REDUCE: best match per anchor gene through the aliases, fp64 epilogue
+        // 8 REDUCE: best match per anchor gene through the aliases, fp64 epilogue
         a.alias = c->b_alias.as<uint32_t>(); a.res = c->b_res.as<uint2>(); a.out = out;
         if ((rc = pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, d, c->shard, a, st))) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));

@@ -42,7 +42,15 @@ struct PcShard {
 };
 
 // One wave task of the alignment kernels: column gene + a range of its bucket.
-struct PcTask { int32_t gene, begin, end, pad; };   // pad: the column's sequence rank (planning only)
+struct PcTask { int32_t gene, begin, end, pad; };   // pad: launch class of the task (planning only)
+
+// Per distinct column sequence q: how its bucket is cut into tasks.
+struct PcTaskPlan {
+    const int32_t* task_rows;         // [U] rows per task of the main variant
+    const uint8_t* q_class;           // [U] launch class (variant * 4 + lanes-per-segment bucket) of the main tasks
+    const uint8_t* q_nseg;            // [U] segments per wave of the main variant
+    const uint8_t* rem_class;         // [U][16] launch class for a remainder of r rows (r = n mod nseg), 255: keep them in the main task
+};
 
 // walker modes (pc_pairs.hip)
 enum { PCW_POCP = 0, PCW_AF = 1, PCW_COUNT = 2, PCW_ENUM = 3, PCW_AAI = 4, PCW_PEQ = 5 };
@@ -81,8 +89,7 @@ int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
 // planning of the alignment batch (pc_plan.hip)
-int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, const int32_t* cls_begin, int ncls, unsigned long long* key, uint32_t* val,
-                        int ntasks, hipStream_t st);
+int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, unsigned long long* key, uint32_t* val, int ntasks, hipStream_t st);
 int pc_launch_task_gather(const PcTask* in, const uint32_t* idx, PcTask* out, int ntasks, hipStream_t st);
 size_t pc_sort_temp_bytes(int64_t n, int bits);
 int pc_sort_pairs(void* temp, size_t temp_bytes, const unsigned long long* key_in, unsigned long long* key_out, const uint32_t* val_in,
@@ -90,9 +97,10 @@ int pc_sort_pairs(void* temp, size_t temp_bytes, const unsigned long long* key_i
 int pc_launch_mark_heads(const unsigned long long* skey, uint32_t* flags, int64_t n, hipStream_t st);
 int pc_launch_unique(const PcDev& d, const unsigned long long* skey, const uint32_t* sval, const uint32_t* flags, const uint32_t* excl,
                      uint32_t* alias, int32_t* bucket_row, uint32_t* start_q, uint32_t* end_q, unsigned long long* totals, int64_t n, hipStream_t st);
-int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, uint32_t* ntask_q, int U, hipStream_t st);
-int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, const uint32_t* task_off_q,
+int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const PcTaskPlan& tp, uint32_t* ntask_q, int U, hipStream_t st);
+int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const PcTaskPlan& tp, const uint32_t* task_off_q,
                         PcTask* tasks, int U, hipStream_t st);
+int pc_launch_class_bounds(const unsigned long long* sorted_key, int ntasks, int ncls, uint32_t* cls_begin /*[ncls+1]*/, hipStream_t st);
 int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st);
 int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st);
 int pc_launch_assemble_table(const double* gathered, int64_t stride, int N, const int32_t* t_rank, const int64_t* t_lbase, double* out, hipStream_t st);
@@ -104,6 +112,7 @@ int pc_nw_num_variants();
 int pc_nw_variant_w(int v);                       // columns per lane of variant v
 int pc_nw_choose_variant(int lb);                 // -1: general fallback
 int pc_nw_task_rows(int lb, int variant);         // rows per workgroup task for that column gene
+int pc_nw_choose_remainder(int lb, int r, int main_variant);   // variant for a bucket's last r < nseg rows, -1: keep them
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, hipStream_t st);
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

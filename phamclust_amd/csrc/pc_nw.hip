@@ -14,6 +14,9 @@
 // Stats are one u32: n_ident in the low half, n_diag in the high half, so the diagonal
 // update is a single add-with-carry: SD = SHdiag + 0x10000 + (a == b).
 // Integer VALU work: no MFMA (there is no dense contraction in this recurrence).
+#include <cstdlib>
+#include <cstring>
+
 #include "pc_common.h"
 #include "../../include/phamclust_hip.h"
 
@@ -502,6 +505,35 @@ int pc_nw_choose_variant(int lb) {
         static const double c1 = getenv("PC_CHOOSE_C1") ? atof(getenv("PC_CHOOSE_C1")) : 0.535;
         const double cost = (W + c0 + c1 * nseg) * pen / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
+    }
+    return best;
+}
+
+// A bucket whose row count is not a multiple of its variant's nseg leaves r = n mod nseg rows for a last wave round in
+// which only r of the nseg segments work.  Those r rows can go to a variant with fewer, longer segments instead:
+// returns that variant, or -1 when staying is as cheap (the cost of a wave round is the step cost of the variant;
+// 30 % margin for the extra workgroup).
+int pc_nw_choose_remainder(int lb, int r, int main_variant) {
+    static const bool off = getenv("PC_REMAINDER") && !strcmp(getenv("PC_REMAINDER"), "0");
+    if (off || lb <= 0 || r <= 0 || main_variant < 0 || main_variant >= g_num_variants) return -1;
+    static const double c0 = getenv("PC_CHOOSE_C0") ? atof(getenv("PC_CHOOSE_C0")) : 0.3;
+    static const double c1 = getenv("PC_CHOOSE_C1") ? atof(getenv("PC_CHOOSE_C1")) : 0.535;
+    auto step_cost = [&](int v, int& nseg) {
+        const int W = g_variant_w[v], G = (lb + W - 1) / W;
+        if (G > 64) { nseg = 0; return 0.0; }
+        nseg = 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
+        const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
+        return (W + c0 + c1 * nseg) * pen;
+    };
+    int nseg0; const double stay = step_cost(main_variant, nseg0);
+    if (nseg0 <= 1 || r >= nseg0) return -1;
+    static const double margin = getenv("PC_REMAINDER_MARGIN") ? atof(getenv("PC_REMAINDER_MARGIN")) : 0.7;
+    int best = -1; double best_cost = margin * stay;
+    for (int v = 0; v < g_num_variants; ++v) {
+        int nseg; const double sc = step_cost(v, nseg);
+        if (!nseg) continue;
+        const double cost = sc * ((r + nseg - 1) / nseg);
+        if (cost < best_cost) { best = v; best_cost = cost; }
     }
     return best;
 }

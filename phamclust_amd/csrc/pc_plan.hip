@@ -95,66 +95,87 @@ int pc_launch_unique(const PcDev& d, const unsigned long long* skey, const uint3
     return PC_OK;
 }
 
-// Workgroup tasks per column sequence q (ntask_q has U+1 slots, the last one zero, for the scan's total)
-__global__ void k_task_count(const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q, const int32_t* __restrict__ task_rows,
+// Workgroup tasks per column sequence q (ntask_q has U+1 slots, the last one zero, for the scan's total).  A bucket of n
+// rows gives ceil(n_main / rows_per_task) tasks of its main variant; when n is not a multiple of that variant's nseg
+// and a narrower variant is cheaper for the r = n mod nseg left-over rows, those form one more task of that variant.
+__device__ __forceinline__ uint32_t pc_split(const PcTaskPlan& tp, int q, uint32_t n, uint32_t& rem_class) {
+    const uint32_t nseg = tp.q_nseg[q], r = nseg > 1 ? n % nseg : 0u;
+    rem_class = r ? tp.rem_class[(size_t)q * 16 + r] : 255u;
+    return rem_class != 255u ? n - r : n;                                 // rows of the main tasks
+}
+__global__ void k_task_count(const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q, PcTaskPlan tp,
                              uint32_t* __restrict__ ntask_q, int U) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > U) return;
     uint32_t nt = 0;
-    if (q < U) { const uint32_t n = end_q[q] - start_q[q], per = (uint32_t)task_rows[q]; nt = (n + per - 1) / per; }
+    if (q < U) {
+        const uint32_t n = end_q[q] - start_q[q], per = (uint32_t)tp.task_rows[q];
+        uint32_t rc; const uint32_t nmain = pc_split(tp, q, n, rc);
+        nt = (nmain + per - 1) / per + (rc != 255u ? 1u : 0u);
+    }
     ntask_q[q] = nt;
 }
-int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, uint32_t* ntask_q, int U, hipStream_t st) {
-    hipLaunchKernelGGL(k_task_count, dim3((U + 1 + 255) / 256), dim3(256), 0, st, start_q, end_q, task_rows, ntask_q, U);
+int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const PcTaskPlan& tp, uint32_t* ntask_q, int U, hipStream_t st) {
+    hipLaunchKernelGGL(k_task_count, dim3((U + 1 + 255) / 256), dim3(256), 0, st, start_q, end_q, tp, ntask_q, U);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
-__global__ void k_task_fill(PcDev d, const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q,
-                            const int32_t* __restrict__ task_rows, const uint32_t* __restrict__ task_off_q, PcTask* __restrict__ tasks, int U) {
+__global__ void k_task_fill(PcDev d, const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q, PcTaskPlan tp,
+                            const uint32_t* __restrict__ task_off_q, PcTask* __restrict__ tasks, int U) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= U) return;
-    const uint32_t b = start_q[q], e = end_q[q], per = (uint32_t)task_rows[q];
+    const uint32_t b = start_q[q], n = end_q[q] - b, per = (uint32_t)tp.task_rows[q];
+    uint32_t rc; const uint32_t nmain = pc_split(tp, q, n, rc);
     uint32_t to = task_off_q[q];
     const int gene = d.q_gene[q];
-    for (uint32_t r = b; r < e; r += per) {
-        PcTask t; t.gene = gene; t.begin = (int32_t)r; t.end = (int32_t)min(e, r + per); t.pad = q;
+    for (uint32_t r = 0; r < nmain; r += per) {
+        PcTask t; t.gene = gene; t.begin = (int32_t)(b + r); t.end = (int32_t)(b + min(nmain, r + per)); t.pad = tp.q_class[q];
         tasks[to++] = t;
     }
+    if (rc != 255u) { PcTask t; t.gene = gene; t.begin = (int32_t)(b + nmain); t.end = (int32_t)(b + n); t.pad = (int32_t)rc; tasks[to] = t; }
 }
-int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const int32_t* task_rows, const uint32_t* task_off_q,
+int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const PcTaskPlan& tp, const uint32_t* task_off_q,
                         PcTask* tasks, int U, hipStream_t st) {
     if (U <= 0) return PC_OK;
-    hipLaunchKernelGGL(k_task_fill, dim3((U + 255) / 256), dim3(256), 0, st, d, start_q, end_q, task_rows, task_off_q, tasks, U);
+    hipLaunchKernelGGL(k_task_fill, dim3((U + 255) / 256), dim3(256), 0, st, d, start_q, end_q, tp, task_off_q, tasks, U);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
-// Longest tasks first inside every launch: a launch's workgroups are dispatched in task order, and a launch that ends
-// on its short tasks drains quickly (the next launch of its hardware queue cannot start before the last workgroup
-// has finished).  key = launch class (position in class order) << 32 | ~(rows * column length); sorted with the same
-// radix sort, the class ranges of the task list do not move.
-__global__ void k_task_keys(PcDev d, const PcTask* __restrict__ tasks, const int32_t* __restrict__ cls_begin, int ncls,
-                            unsigned long long* __restrict__ key, uint32_t* __restrict__ val, int ntasks) {
+// The task list is sorted by (launch class, longest first): inside a launch the workgroups are dispatched in task
+// order, the next launch of the same hardware queue cannot start before the last workgroup has finished, and a
+// launch that ends on its short tasks drains quickly.  key = class << 32 | ~(rows * column length).
+__global__ void k_task_keys(PcDev d, const PcTask* __restrict__ tasks, unsigned long long* __restrict__ key, uint32_t* __restrict__ val, int ntasks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntasks) return;
     const PcTask t = tasks[i];
-    int lo = 0, hi = ncls - 1;                                           // class of column rank t.pad
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cls_begin[mid] <= t.pad) lo = mid; else hi = mid - 1; }
-    const uint32_t work = (uint32_t)(t.end - t.begin) * (uint32_t)d.gene_len[t.gene];
-    key[i] = ((unsigned long long)lo << 32) | (0xffffffffu - work);
+    const int lb = d.gene_len[t.gene];
+    const uint32_t work = (uint32_t)(t.end - t.begin) * (uint32_t)lb;
+    key[i] = ((unsigned long long)(uint32_t)t.pad << 32) | (0xffffffffu - work);
     val[i] = (uint32_t)i;
 }
 __global__ void k_task_gather(const PcTask* __restrict__ in, const uint32_t* __restrict__ idx, PcTask* __restrict__ out, int ntasks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ntasks) out[i] = in[idx[i]];
 }
-int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, const int32_t* cls_begin, int ncls, unsigned long long* key, uint32_t* val,
-                        int ntasks, hipStream_t st) {
+// cls_begin[c] = first sorted task of class >= c (so class c owns [cls_begin[c], cls_begin[c+1])); one thread per class
+__global__ void k_class_bounds(const unsigned long long* __restrict__ key, int ntasks, int ncls, uint32_t* __restrict__ cls_begin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncls) return;
+    int lo = 0, hi = ntasks;                                              // first i with (key[i] >> 32) >= c
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(key[mid] >> 32) >= c) hi = mid; else lo = mid + 1; }
+    cls_begin[c] = (uint32_t)lo;
+}
+int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, unsigned long long* key, uint32_t* val, int ntasks, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
-    hipLaunchKernelGGL(k_task_keys, dim3((ntasks + 255) / 256), dim3(256), 0, st, d, tasks, cls_begin, ncls, key, val, ntasks);
+    hipLaunchKernelGGL(k_task_keys, dim3((ntasks + 255) / 256), dim3(256), 0, st, d, tasks, key, val, ntasks);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 int pc_launch_task_gather(const PcTask* in, const uint32_t* idx, PcTask* out, int ntasks, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
     hipLaunchKernelGGL(k_task_gather, dim3((ntasks + 255) / 256), dim3(256), 0, st, in, idx, out, ntasks);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
+int pc_launch_class_bounds(const unsigned long long* sorted_key, int ntasks, int ncls, uint32_t* cls_begin, hipStream_t st) {
+    hipLaunchKernelGGL(k_class_bounds, dim3((ncls + 1 + 63) / 64), dim3(64), 0, st, sorted_key, ntasks, ncls, cls_begin);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
