@@ -310,16 +310,26 @@ __global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a)
             const int ls = ss[m] - s0, lt = kk[m] - k0;
             const uint32_t* rps = d.rankpre + (int64_t)ss[m] * d.Wb + w0;
             const uint32_t* rpt = d.rankpre + (int64_t)tt[m] * d.Wb + w0;
-            for (int w = 0; w < wn; ++w) {
-                const uint64_t sw = rs[ls][w], tw = rt[lt][w];
-                uint64_t x = sw & tw;
-                if (!x) continue;
-                const uint32_t bs = rps[w], bt = rpt[w];
-                while (x) {
-                    const int b = __ffsll((long long)x) - 1;
-                    x &= x - 1;
-                    const uint64_t below = (1ULL << b) - 1;
-                    pc_visit<MODE>(d, a, acc[m], bs + __popcll(sw & below), bt + __popcll(tw & below), cells, rbytes);
+            // A pair shares ~3 of its ~80 bitmap words, but some lane of the wave has a hit in almost every word: visiting
+            // inside the word scan would run the (divergent, memory-touching) visit body ~70 times per pair slot.  So the
+            // scan only records which words intersect (branch-free, 32 words per mask), and the visits then loop over the
+            // set bits of that mask -- as many iterations as the busiest lane has shared words.  Order stays ascending.
+            for (int wb = 0; wb < wn; wb += 32) {
+                const int we = min(32, wn - wb);
+                uint32_t nz = 0;
+                for (int i = 0; i < we; ++i) nz |= ((rs[ls][wb + i] & rt[lt][wb + i]) != 0 ? 1u : 0u) << i;
+                while (nz) {
+                    const int w = wb + __ffs((int)nz) - 1;
+                    nz &= nz - 1;
+                    const uint64_t sw = rs[ls][w], tw = rt[lt][w];
+                    uint64_t x = sw & tw;
+                    const uint32_t bs = rps[w], bt = rpt[w];
+                    while (x) {
+                        const int b = __ffsll((long long)x) - 1;
+                        x &= x - 1;
+                        const uint64_t below = (1ULL << b) - 1;
+                        pc_visit<MODE>(d, a, acc[m], bs + __popcll(sw & below), bt + __popcll(tw & below), cells, rbytes);
+                    }
                 }
             }
         }
