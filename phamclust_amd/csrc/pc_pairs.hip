@@ -17,7 +17,7 @@
 #include "../../include/phamclust_hip.h"
 
 #define TS 32          // tile edge (genomes)
-#define WCH 96         // bitmap words staged per chunk (P <= 6144 in one chunk)
+#define WCH 32         // bitmap words staged per chunk (17 KB of LDS per workgroup: nine workgroups per CU hide the staging latency)
 
 // ---------------------------------------------------------------------------------
 // round(x, 6) exactly as CPython: decimal(x) correctly rounded half-even to 6 places,
