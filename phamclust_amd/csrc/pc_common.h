@@ -11,7 +11,7 @@
 // rows; rows are dealt to 4*nseg slots, so a wave receives ceil(R / (4 nseg)) * nseg of them: 208 is the
 // largest R for which that is <= 64 for every nseg in 1..16.
 #define PC_TASK_ROWS 208
-#define PC_TASK_BUDGET 32768          // cell slots per row stream of a task (pc_nw_task_rows)
+#define PC_TASK_BUDGET 49152          // cell slots per row stream of a task (pc_nw_task_rows)
 #define PC_MAX_W 64           // widest systolic variant: 64 lanes * 64 columns = 4096 columns
 
 // Device view of the uploaded genomes (all pointers are HBM).
