@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PC_VERSION 110   /* 0.1.1: pc_stats gained n_distinct_alignments / n_distinct_cells */
+#define PC_VERSION 120   /* 0.2.0: tie-rule table (pc_set_tie_rule), pinned-host fills */
 
 typedef enum {
     PC_OK = 0,
@@ -143,6 +143,19 @@ int pc_assemble_dev(pc_ctx* ctx, const void* gathered_dev, int world, void* out_
  */
 int pc_align_pairs(pc_ctx* ctx, const int32_t* a_gene, const int32_t* b_gene, int64_t n, int variant,
                    int32_t* n_ident, int32_t* n_diag);
+
+/*
+ * Tie-rule table of the aligner.  parasail resolves co-optimal alignments by three local rules (SURVEY.md 8c
+ * item 4) that are recalled, not pinned (its source is absent); every alignment kernel exists for all 8
+ * combinations, selected per context.  Bits: 1 = H prefers INS (E) over DEL (F) when both tie (default DEL first);
+ * 2 = E opens when open == extend (default extends); 4 = F opens when open == extend (default extends).
+ * Rule 0 is the default (build-time PC_TIE_RULE_DEFAULT, or environment PC_TIE_RULE at context creation).
+ * Affects aai / peq only.  Replaces nothing in the reference: it is the handle by which a maintainer holding real
+ * parasail vectors re-pins metrics.py:174-175.
+ */
+#define PC_NUM_TIE_RULES 8
+int pc_set_tie_rule(pc_ctx* ctx, int rule);
+int pc_get_tie_rule(const pc_ctx* ctx);
 
 /* Test / tuning hook: HIP-event milliseconds of the alignment kernels of the last pc_align_pairs call. */
 float pc_last_align_ms(const pc_ctx* ctx);

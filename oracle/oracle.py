@@ -66,6 +66,9 @@ def lib():
         L.pco_pairs.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, _i32p, _i32p, ctypes.c_int64, _f64p, ctypes.c_int]
         L.pco_blosum62.argtypes = [ctypes.c_int, ctypes.c_int]
         L.pco_map.argtypes = [ctypes.c_int]
+        L.pco_set_tie_rule.argtypes = [ctypes.c_int]
+        L.pco_set_tie_rule.restype = None
+        L.pco_tie_sensitivity.argtypes = [ctypes.POINTER(_Packed), _i32p, _i32p, ctypes.c_int64, _f64p, _f64p, _i64p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -175,6 +178,52 @@ def fill_rows(packed, metric, row_begin, row_end, as_distance=True, nthreads=0):
 
 def n_threads():
     return lib().pco_threads()
+
+
+# ---------------------------------------------------------------------------
+# Tie-break rule table of the aligner (pc_oracle.c, "Tie-break rule table").  Rule 0 is SURVEY 8c as recalled.
+# ---------------------------------------------------------------------------
+N_TIE_RULES = 16            # bit 3 (gap state before DIAG) is oracle-only; the HIP kernels implement rules 0..7
+TIE_RULE_BITS = {1: "H pointer: INS (E) before DEL (F) when both tie", 2: "E pointer: open on open == extend",
+                 4: "F pointer: open on open == extend", 8: "H pointer: a tying gap state before DIAG"}
+
+
+def set_tie_rule(rule):
+    """Process-wide; every aligner entry point of the C oracle (and py_aai through nw_traceback) follows it."""
+    lib().pco_set_tie_rule(int(rule))
+
+
+def get_tie_rule():
+    return lib().pco_get_tie_rule()
+
+
+class tie_rule:
+    """``with tie_rule(r): ...`` -- restores rule 0 afterwards."""
+
+    def __init__(self, rule):
+        self.rule = rule
+
+    def __enter__(self):
+        set_tie_rule(self.rule)
+
+    def __exit__(self, *exc):
+        set_tie_rule(0)
+
+
+def tie_sensitivity(packed, s_idx, t_idx, nthreads=0):
+    """All 16 rule combinations in one pass over the listed genome pairs.
+    Returns (aai_sim[n,16], peq_sim[n,16], counters[16,8]); counter columns: alignments, changed (ident or length),
+    ident changed, length changed, max |d ident|, max |d length|, identity fraction changed, unused."""
+    s_idx = np.ascontiguousarray(s_idx, dtype=np.int32)
+    t_idx = np.ascontiguousarray(t_idx, dtype=np.int32)
+    assert (s_idx < t_idx).all()
+    n = s_idx.shape[0]
+    aai = np.zeros((n, N_TIE_RULES), dtype=np.float64)
+    peq = np.zeros((n, N_TIE_RULES), dtype=np.float64)
+    counters = np.zeros((N_TIE_RULES, 8), dtype=np.int64)
+    lib().pco_tie_sensitivity(ctypes.byref(_struct(packed)), _ptr(s_idx, _i32p), _ptr(t_idx, _i32p), n, _ptr(aai, _f64p),
+                              _ptr(peq, _f64p), _ptr(counters, _i64p), nthreads)
+    return aai, peq, counters
 
 
 # ---------------------------------------------------------------------------

@@ -96,7 +96,13 @@ struct pc_ctx {
     hipStream_t aux[kAux] = {};             // alignment launches of different classes overlap on these
     hipEvent_t aux_ev[kAux + 1] = {};
     int n_streams = kAux + 1;               // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
+    int tie_rule = 0;                       // row of the aligner's tie-rule table (pc_set_tie_rule)
+    bool busy = false;                      // ev[3] was recorded on a caller's stream and not waited for yet
 };
+
+#ifndef PC_TIE_RULE_DEFAULT
+#define PC_TIE_RULE_DEFAULT 0
+#endif
 
 static int set_device(pc_ctx* c) { PC_HIP(hipSetDevice(c->device)); return PC_OK; }
 
@@ -115,6 +121,8 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     for (int i = 0; i < pc_ctx::kAux && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
     for (int i = 0; i <= pc_ctx::kAux && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
     if (const char* env = getenv("PC_ALIGN_STREAMS")) { int v = atoi(env); if (v >= 1 && v <= pc_ctx::kAux + 1) c->n_streams = v; }
+    c->tie_rule = PC_TIE_RULE_DEFAULT;
+    if (const char* env = getenv("PC_TIE_RULE")) { int v = atoi(env); if (v >= 0 && v < PC_NUM_TIE_RULES) c->tie_rule = v; }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_plan, 4096, hipHostMallocDefault);
     if (e != hipSuccess) { pc_set_error("pc_ctx_create: %s", hipGetErrorString(e)); pc_ctx_destroy(c); return PC_ERR_HIP; }
     *out = c;
@@ -484,7 +492,7 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
                               nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
-                              variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, ls);
+                              variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, c->tie_rule, ls);
         if (rc != PC_OK) return rc;
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) % c->n_streams;
@@ -744,7 +752,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
             scratch = c->b_scratch.p;
         }
         rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[cl], nt, c->b_bucket_row.as<int32_t>(),
-                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], 0, st);
+                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], 0, c->tie_rule, st);
         if (rc != PC_OK) { cleanup(); return rc; }
     }
     (void)hipEventRecord(c->ev[2], st);
@@ -761,6 +769,14 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
 }
 
 extern "C" float pc_last_align_ms(const pc_ctx* c) { return c ? c->last_align_ms : -1.f; }
+
+extern "C" int pc_set_tie_rule(pc_ctx* c, int rule) {
+    if (!c) { pc_set_error("pc_set_tie_rule: NULL context"); return PC_ERR_ARG; }
+    if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_set_tie_rule: rule %d not in 0..%d", rule, PC_NUM_TIE_RULES - 1); return PC_ERR_ARG; }
+    c->tie_rule = rule;
+    return PC_OK;
+}
+extern "C" int pc_get_tie_rule(const pc_ctx* c) { return c ? c->tie_rule : -1; }
 
 // test hook for the device round(x, 6)
 extern "C" int pc_round6_probe(pc_ctx* c, const double* in, double* out, int64_t n) {

@@ -114,5 +114,5 @@ int pc_nw_choose_variant(int lb);                 // -1: general fallback
 int pc_nw_task_rows(int lb, int variant);         // rows per workgroup task for that column gene
 int pc_nw_choose_remainder(int lb, int r, int main_variant);   // variant for a bucket's last r < nseg rows, -1: keep them
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, hipStream_t st);
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, hipStream_t st);
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

@@ -9,6 +9,10 @@
 //   E(i,j) = max(H(i,j-1)-11, E(i,j-1)-1)   ties -> extend      (gap in query, "INS")
 //   F(i,j) = max(H(i-1,j)-11, F(i-1,j)-1)   ties -> extend      (gap in ref,   "DEL")
 //   H(i,j) = max(H(i-1,j-1)+S, E, F)        ties -> DIAG, then F, then E
+// Those three tie-breaks are rule 0 of the TIE-RULE TABLE below (PC_TIE_*): parasail's source is not available
+// (SURVEY.md 8c), so each is a switch -- every kernel exists for all 8 combinations and pc_set_tie_rule() picks
+// one at run time (the CPU checker under tests/ has the same switch).  tests/golden/tie_sensitivity.json holds
+// what each switch is worth.
 // Scores are kept as Ho = H - 11 ("already opened"), which is what both E of the next
 // column and F of the next row consume; the substitution profile is biased by +11.
 // Stats are one u32: n_ident in the low half, n_diag in the high half, so the diagonal
@@ -52,18 +56,24 @@ __constant__ int8_t c_b62[24][24] = {
 // (i-1,j), Hod/SHd from (i-1,j-1), sp = S(a_i,b_j)+11, eq = (a_i == b_j).  Out: Ho,E,F,SH,SE,SF.
 struct PcCell { int Ho, E, F; uint32_t SH, SE, SF; };
 
+// TIE-RULE TABLE (bits of `rule`; include/phamclust_hip.h documents the same numbering):
+//   bit 0  H takes a gap state and E == F:   0: F (DEL) before E (INS)        1: E before F
+//   bit 1  E: open == extend:                0: extend (open iff strictly >)  1: open
+//   bit 2  F: open == extend:                0: extend                        1: open
+// DIAG always wins a tie with a gap state.  This C++ cell (general kernel) reads the rule at run time; the
+// systolic kernel's asm cell is instantiated per rule (PC_TIE_* strings below).
 __device__ __forceinline__ PcCell pc_cell(int Hol, int El, uint32_t SHl, uint32_t SEl, int Hou, int Fu, uint32_t SHu,
-                                          uint32_t SFu, int Hod, uint32_t SHd, int sp, bool eq) {
+                                          uint32_t SFu, int Hod, uint32_t SHd, int sp, bool eq, int rule) {
     PcCell c;
     const int Ee = El - PC_EXT, Fe = Fu - PC_EXT;
     c.E = max(Hol, Ee);
-    c.SE = (Hol > Ee) ? SHl : SEl;               // strictly greater opens; ties extend
+    c.SE = ((rule & 2) ? Hol >= Ee : Hol > Ee) ? SHl : SEl;
     c.F = max(Hou, Fe);
-    c.SF = (Hou > Fe) ? SHu : SFu;
+    c.SF = ((rule & 4) ? Hou >= Fe : Hou > Fe) ? SHu : SFu;
     const int D = Hod + sp;
     const int H = max(max(D, c.E), c.F);
     const uint32_t SD = SHd + 0x10000u + (eq ? 1u : 0u);
-    const uint32_t ST = (H == c.F) ? c.SF : c.SE;   // two flat selects: nested ?: becomes control flow
+    const uint32_t ST = (rule & 1) ? ((H == c.E) ? c.SE : c.SF) : ((H == c.F) ? c.SF : c.SE);   // flat selects: nested ?: becomes control flow
     c.SH = (H == D) ? SD : ST;
     c.Ho = H - PC_OPEN;
     return c;
@@ -78,7 +88,7 @@ __device__ __forceinline__ PcCell pc_cell(int Hol, int El, uint32_t SHl, uint32_
 __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __restrict__ tasks, int ntasks,
                                                    const int32_t* __restrict__ bucket_row,
                                                    const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res,
-                                                   int4* __restrict__ scratch, int64_t scratch_stride, int ppos) {
+                                                   int4* __restrict__ scratch, int64_t scratch_stride, int ppos, int rule) {
     __shared__ int8_t tab[24][24];
     for (int i = threadIdx.x; i < 576; i += 64) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + PC_OPEN);
     __syncthreads();
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
                 const int bj = bp[j];
                 const int4 up = sc[(int64_t)j * 64 + lane];
                 const PcCell c = pc_cell(Hol, El, SHl, SEl, up.x, up.y, (uint32_t)up.z, (uint32_t)up.w, Hod, SHd,
-                                         trow[min(bj, 23)], ai == bj || (ppos && trow[min(bj, 23)] > PC_OPEN));   // ppos: '+' columns count too
+                                         trow[min(bj, 23)], ai == bj || (ppos && trow[min(bj, 23)] > PC_OPEN), rule);   // ppos: '+' columns count too
                 if (live) sc[(int64_t)j * 64 + lane] = make_int4(c.Ho, c.F, (int)c.SH, (int)c.SF);
                 Hod = up.x; SHd = (uint32_t)up.z;
                 Hol = c.Ho; El = c.E; SHl = c.SH; SEl = c.SE;
@@ -173,22 +183,22 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
 // One cell.  In: D, SD (this cell's diagonal candidates), chain (Hol, El, SHl, SEl), row code ac.
 // In/out (in place): column state Hou -> Ho, Fu -> F, SHu -> SH, SFu -> SF.
 // Out: E, SE (chain), and for the next cell Dn = old Hou + sp_next, SDn = old SHu + 0x10000 + (ac == bcn).
-#define PC_CELL_BODY(CMP_LINE, NEXT_D, NEXT_SD)                                                 \
+#define PC_CELL_BODY(E_OPENS, F_OPENS, H_GAP, T_PICK, CMP_LINE, NEXT_D, NEXT_SD)                \
     asm volatile(                                                                               \
-        "v_cmp_gt_i32 %[c0], %[Hol], %[El]\n\t"                                                 \
-        "v_cmp_gt_i32 %[c1], %[Hou], %[Fu]\n\t"                                                 \
+        E_OPENS                                                                                 \
+        F_OPENS                                                                                 \
         CMP_LINE                                                                                \
         "v_max_i32 %[E], %[Hol], %[El]\n\t"                                                     \
         "v_max_i32 %[Fu], %[Hou], %[Fu]\n\t"                                                    \
         NEXT_D                                                                                  \
         "v_max3_i32 %[H], %[D], %[E], %[Fu]\n\t"                                                \
-        "v_cmp_eq_u32 %[c3], %[H], %[Fu]\n\t"                                                   \
+        H_GAP                                                                                   \
         "v_cmp_eq_u32 %[c4], %[H], %[D]\n\t"                                                    \
         "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
         "v_cndmask_b32 %[SFu], %[SFu], %[SHu], %[c1]\n\t"                                       \
         NEXT_SD                                                                                 \
         "v_add_u32 %[Hou], -10, %[H]\n\t"                                                       \
-        "v_cndmask_b32 %[T], %[SE], %[SFu], %[c3]\n\t"                                          \
+        T_PICK                                                                                  \
         "v_cndmask_b32 %[SHu], %[T], %[SD], %[c4]\n\t"                                          \
         : [E] "=&v"(E), [SE] "=&v"(SE), [H] "=&v"(H), [T] "=&v"(T),                                              \
           [Dn] "=&v"(Dn), [SDn] "=&v"(SDn), [Hou] "+v"(Hou), [Fu] "+v"(Fu), [SHu] "+v"(SHu), [SFu] "+v"(SFu),    \
@@ -200,30 +210,53 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
 #define PC_NEXT_D(SEL) "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t"
 #define PC_NEXT_SD "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
 
-template <int NEXT_BYTE>   // byte of pwn holding the next cell's score; -1: last cell of the lane
+// The tie-rule table of the asm cell: the only instructions that differ between the 8 rules.
+#define PC_TIE_E_EXTENDS "v_cmp_gt_i32 %[c0], %[Hol], %[El]\n\t"      /* E opens iff open > extend  (rule bit 1 = 0) */
+#define PC_TIE_E_OPENS "v_cmp_ge_i32 %[c0], %[Hol], %[El]\n\t"        /* E opens iff open >= extend (rule bit 1 = 1) */
+#define PC_TIE_F_EXTENDS "v_cmp_gt_i32 %[c1], %[Hou], %[Fu]\n\t"      /* rule bit 2 = 0 */
+#define PC_TIE_F_OPENS "v_cmp_ge_i32 %[c1], %[Hou], %[Fu]\n\t"        /* rule bit 2 = 1 */
+#define PC_TIE_H_DEL_FIRST "v_cmp_eq_u32 %[c3], %[H], %[Fu]\n\t"      /* H == F takes F's stats, else E's (rule bit 0 = 0) */
+#define PC_TIE_T_DEL_FIRST "v_cndmask_b32 %[T], %[SE], %[SFu], %[c3]\n\t"
+#define PC_TIE_H_INS_FIRST "v_cmp_eq_u32 %[c3], %[H], %[E]\n\t"       /* H == E takes E's stats, else F's (rule bit 0 = 1) */
+#define PC_TIE_T_INS_FIRST "v_cndmask_b32 %[T], %[SFu], %[SE], %[c3]\n\t"
+
+template <int NEXT_BYTE, int RULE>   // NEXT_BYTE: byte of pwn holding the next cell's score; -1: last cell of the lane
 __device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl,
                                             int& Hou, int& Fu, uint32_t& SHu, uint32_t& SFu, int& E, uint32_t& SE,
                                             int& Dn, uint32_t& SDn, int ac, int bcn, uint32_t pwn, uint32_t K) {
     int H; uint32_t T;
     unsigned long long c0, c1, c2, c3, c4;
-    if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(PC_CMP("BYTE_0"), PC_NEXT_D("BYTE_0"), PC_NEXT_SD);
-    else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(PC_CMP("BYTE_1"), PC_NEXT_D("BYTE_1"), PC_NEXT_SD);
-    else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(PC_CMP("BYTE_2"), PC_NEXT_D("BYTE_2"), PC_NEXT_SD);
-    else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(PC_CMP("BYTE_3"), PC_NEXT_D("BYTE_3"), PC_NEXT_SD);
-    else { PC_CELL_BODY("", "", ""); Dn = 0; SDn = 0; }
+#define PC_CELL_RULE(EO, FO, HG, TP)                                                                      \
+    do {                                                                                                  \
+        if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_0"), PC_NEXT_D("BYTE_0"), PC_NEXT_SD);      \
+        else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_1"), PC_NEXT_D("BYTE_1"), PC_NEXT_SD); \
+        else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_2"), PC_NEXT_D("BYTE_2"), PC_NEXT_SD); \
+        else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_3"), PC_NEXT_D("BYTE_3"), PC_NEXT_SD); \
+        else { PC_CELL_BODY(EO, FO, HG, TP, "", "", ""); Dn = 0; SDn = 0; }                                                  \
+    } while (0)
+    static_assert(RULE >= 0 && RULE < 8, "tie rule");
+    if constexpr (RULE == 0) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_EXTENDS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
+    else if constexpr (RULE == 1) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_EXTENDS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
+    else if constexpr (RULE == 2) PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_EXTENDS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
+    else if constexpr (RULE == 3) PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_EXTENDS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
+    else if constexpr (RULE == 4) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_OPENS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
+    else if constexpr (RULE == 5) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_OPENS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
+    else if constexpr (RULE == 6) PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_OPENS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
+    else PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_OPENS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
+#undef PC_CELL_RULE
 }
 
-template <int W, int C>
+template <int W, int C, int RULE>
 struct PcRow {          // compile-time unrolled sweep over the lane's W columns
     static __device__ __forceinline__ void run(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl, int (&Hou)[W],
                                                int (&Fu)[W], uint32_t (&SHu)[W], uint32_t (&SFu)[W], const uint32_t (&bc)[(W + 3) / 4],
                                                const uint32_t (&pw)[(W + 3) / 4], int ac, uint32_t K, int& E_out, uint32_t& SE_out) {
         int E, Dn; uint32_t SE, SDn;
         constexpr int NB = (C + 1 < W) ? ((C + 1) & 3) : -1;
-        pc_cell_asm<NB>(D, SD, Hol, El, SHl, SEl, Hou[C], Fu[C], SHu[C], SFu[C], E, SE, Dn, SDn, ac,
+        pc_cell_asm<NB, RULE>(D, SD, Hol, El, SHl, SEl, Hou[C], Fu[C], SHu[C], SFu[C], E, SE, Dn, SDn, ac,
                         (int)bc[(C + 1 < W) ? ((C + 1) >> 2) : 0], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
         if constexpr (C + 1 < W)
-            PcRow<W, C + 1>::run(Dn, SDn, Hou[C], E, SHu[C], SE, Hou, Fu, SHu, SFu, bc, pw, ac, K, E_out, SE_out);
+            PcRow<W, C + 1, RULE>::run(Dn, SDn, Hou[C], E, SHu[C], SE, Hou, Fu, SHu, SFu, bc, pw, ac, K, E_out, SE_out);
         else { E_out = E; SE_out = SE; }
     }
 };
@@ -261,7 +294,7 @@ typedef uint32_t pc_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const pc_u32x2 pc_lds_u32x2;
 typedef __attribute__((address_space(3))) const pc_u32x4 pc_lds_u32x4;
 
-template <int W>
+template <int W, int RULE>
 __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
                                                                const uint32_t* __restrict__ bucket_dest,
@@ -455,7 +488,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
                          : "+v"(D0), "+v"(Hol) : "v"(v_neg), "s"(rstm), "s"(hr));
         }
         p_Hol = Hol; p_SHl = SHl;
-        PcRow<W, 0>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, (int)a, K, o_E, o_SE);
+        PcRow<W, 0, RULE>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, (int)a, K, o_E, o_SE);
         if ((lastm & outm) != 0) {                                        // a row's last cell left the lane holding column lb-1
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
             if ((a & PCF_LAST) && is_out) {
@@ -559,16 +592,31 @@ int pc_nw_task_rows(int lb, int variant) {
     return (int)(rows > PC_TASK_ROWS ? PC_TASK_ROWS : rows);
 }
 
-template <int W>
-static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                           const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
+template <int W, int RULE>
+static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
+                                const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
     const int ND = (W + 3) / 4;
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
     const size_t lds = (size_t)(144 + PC_WAVES * PC_WREG) * 4 + (size_t)24 * Gmax * ND * 4;
-    hipLaunchKernelGGL(k_nw_systolic<W>, dim3((unsigned)ntasks), dim3(64 * PC_WAVES), lds, st, d, tasks, bucket_row, bucket_dest, res);
+    hipLaunchKernelGGL((k_nw_systolic<W, RULE>), dim3((unsigned)ntasks), dim3(64 * PC_WAVES), lds, st, d, tasks, bucket_row, bucket_dest, res);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d> launch: %s", W, hipGetErrorString(e)); return PC_ERR_HIP; }
+    if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d,%d> launch: %s", W, RULE, hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
+}
+template <int W>
+static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
+                           const uint32_t* bucket_dest, uint2* res, int max_lb, int rule, hipStream_t st) {
+    switch (rule) {
+    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
+    }
 }
 
 size_t pc_nw_fallback_scratch_bytes(int max_lb) {
@@ -581,15 +629,16 @@ size_t pc_nw_fallback_scratch_bytes(int max_lb) {
 }
 
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, hipStream_t st) {
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
+    if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_launch_nw: tie rule %d out of range", rule); return PC_ERR_ARG; }
     if (variant >= 0 && ppos) { pc_set_error("pc_launch_nw: ppos runs on the general kernel only"); return PC_ERR_ARG; }
     if (variant >= 0) {
         if (variant >= g_num_variants || max_lb > 64 * g_variant_w[variant]) {
             pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
         }
         switch (g_variant_w[variant]) {
-#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, rule, st);
         PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
         PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24) PC_CASE(32) PC_CASE(48) PC_CASE(64)
 #undef PC_CASE
@@ -603,7 +652,7 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
     if (blocks > 1024) blocks = 1024;
     if (blocks > (size_t)ntasks) blocks = (size_t)ntasks;
     hipLaunchKernelGGL(k_nw_general, dim3((unsigned)blocks), dim3(64), 0, st, d, tasks, ntasks, bucket_row, bucket_dest, res,
-                       (int4*)scratch, (int64_t)(per_block / sizeof(int4)), ppos);
+                       (int4*)scratch, (int64_t)(per_block / sizeof(int4)), ppos, rule);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_nw_general launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;

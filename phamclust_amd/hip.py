@@ -43,7 +43,7 @@ class PcStats(ctypes.Structure):
 
 EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
-           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe"]
+           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule"]
 
 _lib = None
 
@@ -88,6 +88,8 @@ def load():
     L.pc_round6_probe.argtypes = [vp, _f64p, _f64p, ctypes.c_int64]
     L.pc_last_align_ms.argtypes = [vp]
     L.pc_last_align_ms.restype = ctypes.c_float
+    L.pc_set_tie_rule.argtypes = [vp, ctypes.c_int]
+    L.pc_get_tie_rule.argtypes = [vp]
     _lib = L
     return L
 
@@ -197,6 +199,13 @@ class Context:
         self._check(self._lib.pc_align_pairs(self._h, _ptr(a, _i32p), _ptr(b, _i32p), n, int(variant),
                                              _ptr(ident, _i32p), _ptr(diag, _i32p)))
         return ident, diag
+
+    def set_tie_rule(self, rule):
+        """Row of the aligner's tie-rule table (include/phamclust_hip.h); 0 = SURVEY 8c as recalled."""
+        self._check(self._lib.pc_set_tie_rule(self._h, int(rule)))
+
+    def tie_rule(self):
+        return int(self._lib.pc_get_tie_rule(self._h))
 
     def last_align_ms(self):
         return float(self._lib.pc_last_align_ms(self._h))

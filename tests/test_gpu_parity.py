@@ -131,6 +131,50 @@ def test_big_buckets_all_segment_counts(gpu_ctx, native_built, w):
     assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
 
 
+@pytest.mark.parametrize("rule", list(range(8)))
+def test_tie_rule_table(gpu_ctx, native_built, rule):
+    """Every row of the aligner's tie-rule table (include/phamclust_hip.h, pc_set_tie_rule): the systolic variants,
+    the general kernel and a whole aai / peq fill equal the oracle switched to the same rule (pco_set_tie_rule), on
+    tie-heavy sequences (3-letter alphabet: co-optimal alignments in most pairs).  Rule 0 = SURVEY 8c as recalled;
+    parasail itself is absent, so which row it follows is unpinned -- tests/golden/tie_sensitivity.json holds what the
+    choice is worth."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    rng = np.random.default_rng(900 + rule)
+    g, h = Genome("cols"), Genome("rows")
+    for i in range(24):
+        alpha = np.array(list("AGS" if i % 2 == 0 else "ACDEFGHIKLMNPQRSTVWY"))
+        g.add(f"c{i:02d}", "".join(alpha[rng.integers(0, len(alpha), int(rng.integers(1, 190)))]))
+    for i in range(60):
+        alpha = np.array(list("AGS" if i % 3 else "ACDEFGHIKLMNPQRSTVWY"))
+        h.add(f"r{i:02d}", "".join(alpha[rng.integers(0, len(alpha), int(rng.integers(1, 190)))]))
+    pk = pack_genomes([g, h])
+    a = np.repeat(np.arange(24, 84, dtype=np.int32), 24)
+    b = np.tile(np.arange(24, dtype=np.int32), 60)
+    small = synth_packed(40, 200, seed=77)
+    try:
+        gpu_ctx.set_tie_rule(rule)
+        assert gpu_ctx.tie_rule() == rule
+        O.set_tie_rule(rule)
+        _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+        gpu_ctx.upload(pk)
+        for variant in (0, -1, 3, 8, 13, 24, 48):
+            ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
+            assert np.array_equal(ident, wi) and np.array_equal(diag, wd), f"rule {rule} variant {variant}"
+        gpu_ctx.upload(small)
+        for metric in ("aai", "peq"):
+            assert np.array_equal(gpu_ctx.fill(metric, as_distance=True), O.fill(small, metric, as_distance=True)), f"rule {rule} {metric}"
+        if rule:                                     # the switch is not a no-op: this data has ties the rule decides
+            O.set_tie_rule(0)
+            _, zi, zd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+            assert not (np.array_equal(zi, wi) and np.array_equal(zd, wd))
+    finally:
+        O.set_tie_rule(0)
+        gpu_ctx.set_tie_rule(0)
+
+
 def test_round6_matches_python(gpu_ctx):
     rng = np.random.default_rng(9)
     xs = np.concatenate([

@@ -63,6 +63,56 @@ def test_aligner_formulations_agree(O):
         assert tb.query.replace("-", "") == a and tb.ref.replace("-", "") == b
 
 
+@pytest.mark.parametrize("rule", list(range(1, 16)))
+def test_aligner_formulations_agree_under_every_tie_rule(O, rule):
+    """The table + traceback walk and the one-pass statistics are two implementations of each tie rule; the
+    multi-rule pass behind tools/tie_sensitivity.py is a third.  All must agree, and the score never moves."""
+    rng = random.Random(50 + rule)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    try:
+        for it in range(400):
+            alpha = aa[:3] if it % 3 else aa
+            a = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 40)))
+            b = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 40)))
+            O.set_tie_rule(0)
+            score0 = O.nw_stats(a, b)[0]
+            O.set_tie_rule(rule)
+            tb = O.nw_traceback(a, b)
+            score, ident, diag = O.nw_stats(a, b)
+            assert score == tb.score == score0
+            assert ident == tb.comp.count("|") and len(tb.query) == len(a) + len(b) - diag
+            assert tb.query.replace("-", "") == a and tb.ref.replace("-", "") == b
+    finally:
+        O.set_tie_rule(0)
+
+
+def test_tie_sensitivity_pass_equals_single_rule_paths(O):
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(24, 120, seed=5)
+    iu = np.triu_indices(packed.n_genomes, 1)
+    aai, peq, counters = O.tie_sensitivity(packed, iu[0], iu[1])
+    assert counters[0, 1] == 0 and (counters[:, 0] == counters[0, 0]).all()
+    try:
+        for rule in range(16):
+            O.set_tie_rule(rule)
+            assert np.array_equal(O.pairs(packed, "aai", iu[0], iu[1], as_distance=False), aai[:, rule])
+            assert np.array_equal(O.pairs(packed, "peq", iu[0], iu[1], as_distance=False), peq[:, rule])
+    finally:
+        O.set_tie_rule(0)
+
+
+def test_tie_sensitivity_report_is_committed_and_consistent():
+    """tests/golden/tie_sensitivity.json (tools/tie_sensitivity.py): the bound DESIGN.md quotes."""
+    import json
+    with open(golden_file("gcs").replace("gcs_distance_matrix.tsv", "tie_sensitivity.json")) as fh:
+        rep = json.load(fh)
+    assert [d["name"] for d in rep["datasets"]] == ["tests/golden/small_input.tsv", "synth(2000,5000)"]
+    for ds in rep["datasets"]:
+        assert len(ds["rules"]) == 16 and ds["rules"][0]["alignments_changed_frac"] == 0.0
+    worst = rep["worst_case_over_rules_1_to_7"]
+    assert 0.0 < worst["alignments_changed_frac"] < 0.05 and worst["max_abs_d_peq"] < 1e-3
+
+
 def test_aligner_known_answers(O):
     """Math-pinned cases: any correct affine NW (11/1, BLOSUM62) must return these."""
     s = "MKTAYIAKQRQISFVKSHFSRQLEERLGLIEVQ"
