@@ -110,6 +110,12 @@ int pc_set_shard(pc_ctx* ctx, int rank, int world);
 int pc_set_shard_balanced(pc_ctx* ctx, int rank, int world);
 int64_t pc_shard_pairs(const pc_ctx* ctx);
 int64_t pc_shard_stride(const pc_ctx* ctx);
+/* The deal in force, for callers that assemble (or check) the gathered shards themselves: target genome t belongs to
+ * rank t_rank[t] and pair (s, t), s < t, sits at index t_lbase[t] + s of that rank's shard.  Both arrays hold N entries. */
+int pc_shard_table(const pc_ctx* ctx, int32_t* t_rank, int64_t* t_lbase);
+/* DP cells behind each target genome (sum over s < t), as counted for the cost-balanced deal; N entries.
+ * PC_ERR_STATE until pc_set_shard_balanced has run for the current upload. */
+int pc_target_costs(const pc_ctx* ctx, uint64_t* cost);
 
 /*
  * matrix_de_novo's fill (matrix.py:479-491) for the six METRICS, whole matrix, one GPU.

@@ -13,6 +13,7 @@ METRICS = dict(gcs=_m.gene_content_similarity, jc=_m.jaccard_coefficient, pocp=_
                af=_m.alignment_fraction, aai=_m.average_aminoacid_identity, peq=_m.proteomic_equivalence_quotient)
 LINKAGES = {"single", "average", "complete"}
 CPUS = cpu_count()
+GPUS = 1                                     # the fill's counterpart of -t: how many GPUs share the pair list
 COLORS = "red,yellow,green"
 METRIC, K_MIN = "peq", 6
 NR_THRESH, NR_LINKAGE = 0.75, "complete"     # 1st pass: glue near-identical genomes together
@@ -44,7 +45,9 @@ _OPTIONS = (
     (None, "-d", "--debug", dict(action="store_true", help="log at DEBUG level")),
     (None, "-n", "--no-sub", dict(action="store_true", help="skip the sub-clustering pass")),
     (None, "-r", "--remove-tmp", dict(action="store_true", help="delete the cache directory at the end (re-runs then recompute the matrix)")),
-    (None, "-t", "--threads", dict(type=int, default=CPUS, help="accepted for compatibility; the six metrics run on the GPU")),
+    (None, "-t", "--threads", dict(type=int, default=CPUS, help="accepted for compatibility; the six metrics run on the GPU (see --gpus)")),
+    (None, "-G", "--gpus", dict(type=int, default=GPUS, help="GPUs of this node to spread the matrix fill over (one process per GPU "
+                                                              "under torch.distributed.run, static pair shard, one RCCL gather)")),
 )
 DEFAULTS = {long.lstrip("-").replace("-", "_"): kw.get("default", False) for _, _, long, kw in _OPTIONS}
 

@@ -83,6 +83,8 @@ struct pc_ctx {
     PcShard shard{};
     bool balanced = false;                  // cost-balanced deal in force (pc_set_shard_balanced): assembly goes through the tables
     std::vector<uint64_t> target_cost;      // DP cells per target genome, computed once per upload
+    std::vector<int32_t> h_t_rank;          // the deal in force, host copy: owner rank of each target genome ...
+    std::vector<int64_t> h_t_lbase;         // ... and where its pairs start inside that rank's shard
     // persistent device arrays
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
     DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
@@ -98,13 +100,40 @@ struct pc_ctx {
     int n_streams = kAux + 1;               // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
     int tie_rule = 0;                       // row of the aligner's tie-rule table (pc_set_tie_rule)
     bool busy = false;                      // ev[3] was recorded on a caller's stream and not waited for yet
+    hipStream_t last_stream = nullptr;      // ... on this stream
 };
 
 #ifndef PC_TIE_RULE_DEFAULT
 #define PC_TIE_RULE_DEFAULT 0
 #endif
 
-static int set_device(pc_ctx* c) { PC_HIP(hipSetDevice(c->device)); return PC_OK; }
+// Every entry point runs on the context's device and leaves the calling thread's current device as it found it
+// (PyTorch and other libraries in the process keep their own idea of "current device").
+struct PcDeviceGuard {
+    int prev = -1, dev = -1; bool ok = true;
+    explicit PcDeviceGuard(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) {
+            hipError_t e = hipSetDevice(dev);
+            if (e != hipSuccess) { pc_set_error("hipSetDevice(%d): %s", dev, hipGetErrorString(e)); ok = false; }
+        }
+    }
+    ~PcDeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    PcDeviceGuard(const PcDeviceGuard&) = delete;
+    PcDeviceGuard& operator=(const PcDeviceGuard&) = delete;
+};
+#define PC_ON_DEVICE(c) PcDeviceGuard pc_guard_((c)->device); if (!pc_guard_.ok) return PC_ERR_HIP
+
+// A fill without stats returns while its kernels still run on the CALLER's stream and still use the context's work
+// buffers and shard tables.  Anything that rewrites those (upload, re-shard, the test hooks, a fill on another
+// stream) first waits for the event the last fill recorded at its end.
+static int wait_last_fill(pc_ctx* c, hipStream_t next_stream, bool same_stream_is_ordered) {
+    if (!c->busy) return PC_OK;
+    if (same_stream_is_ordered && next_stream == c->last_stream) return PC_OK;
+    PC_HIP(hipEventSynchronize(c->ev[3]));
+    c->busy = false;
+    return PC_OK;
+}
 
 extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     if (!out) { pc_set_error("pc_ctx_create: out is NULL"); return PC_ERR_ARG; }
@@ -115,7 +144,8 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     pc_ctx* c = new (std::nothrow) pc_ctx();
     if (!c) { pc_set_error("out of host memory"); return PC_ERR_ARG; }
     c->device = device_id;
-    hipError_t e = hipSetDevice(device_id);
+    PcDeviceGuard guard(device_id);
+    hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < pc_ctx::kAux && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
@@ -131,7 +161,8 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
 
 extern "C" void pc_ctx_destroy(pc_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    PcDeviceGuard guard(c->device);
+    if (c->busy) (void)hipEventSynchronize(c->ev[3]);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
                       &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
@@ -176,6 +207,7 @@ static int pc_class_of(int lb, int variant) {
 static int apply_shard(pc_ctx* c, int rank, int world) {
     const int N = c->dev.N;
     std::vector<int32_t> owned; std::vector<int64_t> lbase;
+    c->h_t_rank.assign(std::max(N, 1), 0); c->h_t_lbase.assign(std::max(N, 1), 0);
     int64_t best = 0;
     for (int r = 0; r < world; ++r) {
         int64_t tot = 0;
@@ -184,6 +216,7 @@ static int apply_shard(pc_ctx* c, int rank, int world) {
             const int64_t t = (int64_t)j * world + pos;
             if (t >= N) { if ((int64_t)j * world >= N) break; else continue; }
             if (r == rank) { owned.push_back((int32_t)t); lbase.push_back(tot); }
+            c->h_t_rank[t] = r; c->h_t_lbase[t] = tot;
             tot += t;
         }
         if (r == rank) { lbase.push_back(tot); c->shard_pairs = tot; }
@@ -201,7 +234,8 @@ static int apply_shard(pc_ctx* c, int rank, int world) {
 
 extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     if (!c || !g) { pc_set_error("pc_upload: NULL argument"); return PC_ERR_ARG; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = PC_OK;
     const int N = g->n_genomes, P = g->n_phams, W = g->words_per_row;
     if (N <= 0 || P < 0 || W != std::max(1, (P + 63) / 64) || g->reserved != 0 || !g->bitmap || !g->nph || !g->ngen || !g->tlen ||
         !g->gene_off || !g->seq_off) {
@@ -220,6 +254,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         fprintf(stderr, "pc_upload %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
+    if ((rc = wait_last_fill(c, nullptr, false))) return rc;
     c->uploaded = false; c->target_cost.clear();
     PC_HIP(hipStreamSynchronize(c->stream));
 
@@ -394,7 +429,8 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
 extern "C" int pc_set_shard(pc_ctx* c, int rank, int world) {
     if (!c || !c->uploaded) { pc_set_error("pc_set_shard: upload first"); return PC_ERR_STATE; }
     if (world < 1 || rank < 0 || rank >= world) { pc_set_error("pc_set_shard: rank %d of %d", rank, world); return PC_ERR_ARG; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = wait_last_fill(c, nullptr, false); if (rc != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(c->stream));
     return apply_shard(c, rank, world);
 }
@@ -405,7 +441,8 @@ extern "C" int pc_set_shard(pc_ctx* c, int rank, int world) {
 extern "C" int pc_set_shard_balanced(pc_ctx* c, int rank, int world) {
     if (!c || !c->uploaded) { pc_set_error("pc_set_shard_balanced: upload first"); return PC_ERR_STATE; }
     if (world < 1 || rank < 0 || rank >= world) { pc_set_error("pc_set_shard_balanced: rank %d of %d", rank, world); return PC_ERR_ARG; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = wait_last_fill(c, nullptr, false); if (rc != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(c->stream));
     const int N = c->dev.N;
     if (c->target_cost.empty()) {
@@ -447,9 +484,24 @@ extern "C" int pc_set_shard_balanced(pc_ctx* c, int rank, int world) {
     c->rank = rank; c->world = world; c->balanced = true;
     if ((rc = upload_vec(c->b_owned, owned)) || (rc = upload_vec(c->b_lbase, lbase)) || (rc = upload_vec(c->b_t_rank, t_rank)) ||
         (rc = upload_vec(c->b_t_lbase, t_lbase))) return rc;
+    c->h_t_rank = t_rank; c->h_t_lbase = t_lbase;
     c->shard.nown = (int32_t)owned.size();
     c->shard.owned = c->b_owned.as<int32_t>();
     c->shard.lbase = c->b_lbase.as<int64_t>();
+    return PC_OK;
+}
+extern "C" int pc_shard_table(const pc_ctx* c, int32_t* t_rank, int64_t* t_lbase) {
+    if (!c || !c->uploaded) { pc_set_error("pc_shard_table: upload first"); return PC_ERR_STATE; }
+    if (!t_rank || !t_lbase) { pc_set_error("pc_shard_table: NULL argument"); return PC_ERR_ARG; }
+    memcpy(t_rank, c->h_t_rank.data(), sizeof(int32_t) * (size_t)c->dev.N);
+    memcpy(t_lbase, c->h_t_lbase.data(), sizeof(int64_t) * (size_t)c->dev.N);
+    return PC_OK;
+}
+extern "C" int pc_target_costs(const pc_ctx* c, uint64_t* cost) {
+    if (!c || !c->uploaded) { pc_set_error("pc_target_costs: upload first"); return PC_ERR_STATE; }
+    if (!cost) { pc_set_error("pc_target_costs: NULL argument"); return PC_ERR_ARG; }
+    if (c->target_cost.size() != (size_t)c->dev.N) { pc_set_error("pc_target_costs: no cost-balanced deal was computed for this upload (pc_set_shard_balanced)"); return PC_ERR_STATE; }
+    memcpy(cost, c->target_cost.data(), sizeof(uint64_t) * (size_t)c->dev.N);
     return PC_OK;
 }
 extern "C" int64_t pc_shard_pairs(const pc_ctx* c) { return c && c->uploaded ? c->shard_pairs : -1; }
@@ -484,7 +536,7 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     constexpr int kAux = pc_ctx::kAux;
     PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
     for (int k = 0; k < kAux; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[kAux], 0));
-    int slot = 0;
+    int slot = 0, first_error = PC_OK;
     for (int i : order) {
         const int nt = (int)(task_begin[i + 1] - task_begin[i]);
         const int variant = ppos ? -1 : variant_of(i);            // percent-positives: general kernel (rare, no CLI route)
@@ -493,15 +545,17 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
                               nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
                               variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, c->tie_rule, ls);
-        if (rc != PC_OK) return rc;
+        if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) % c->n_streams;
     }
+    // join the auxiliary streams back into the caller's stream -- also after a failed launch, so that what was
+    // already queued on them is ordered before anything the caller does next
     for (int k = 0; k < kAux; ++k) {
         PC_HIP(hipEventRecord(c->aux_ev[k], c->aux[k]));
         PC_HIP(hipStreamWaitEvent(st, c->aux_ev[k], 0));
     }
-    return PC_OK;
+    return first_error;
 }
 
 static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
@@ -510,9 +564,11 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     const int ppos = metric == PC_AAI_PPOS;
     if (ppos) metric = PC_AAI;
     if (!out) { pc_set_error("fill: out is NULL"); return PC_ERR_ARG; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = PC_OK;
     // st == NULL is HIP's legacy default stream, used as such: a caller whose producers / consumers run on it (PyTorch's
     // default stream has handle 0) is ordered with these launches; the library's own streams are non-blocking
+    if ((rc = wait_last_fill(c, st, true))) return rc;
     const PcDev& d = c->dev;
     const int64_t Lp = c->shard_pairs;
     pc_stats local; memset(&local, 0, sizeof(local));
@@ -628,8 +684,10 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         if ((rc = pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, d, c->shard, a, st))) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
     }
+    c->busy = true; c->last_stream = st;
     if (stats) {
         PC_HIP(hipEventSynchronize(c->ev[3]));
+        c->busy = false;
         PC_HIP(hipEventElapsedTime(&local.ms_total, c->ev[0], c->ev[3]));
         if (metric >= PC_AAI) {
             PC_HIP(hipEventElapsedTime(&local.ms_plan, c->ev[0], c->ev[1]));
@@ -651,18 +709,20 @@ extern "C" int pc_fill_dev(pc_ctx* c, int metric, int as_distance, void* out_dev
 extern "C" int pc_fill(pc_ctx* c, int metric, int as_distance, double* out_condensed, pc_stats* stats) {
     if (!c || !c->uploaded) { pc_set_error("pc_fill: upload first"); return PC_ERR_STATE; }
     if (!out_condensed) { pc_set_error("pc_fill: out is NULL"); return PC_ERR_ARG; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = PC_OK;
     const int64_t np = (int64_t)c->dev.N * (c->dev.N - 1) / 2;
     if ((rc = c->b_out.ensure(std::max<int64_t>(np, 1) * 8))) return rc;
     if ((rc = pc_fill_dev(c, metric, as_distance, c->b_out.p, c->stream, stats))) return rc;
     if (np) PC_HIP(hipMemcpyAsync(out_condensed, c->b_out.p, np * 8, hipMemcpyDeviceToHost, c->stream));
     PC_HIP(hipStreamSynchronize(c->stream));
+    c->busy = false;
     return PC_OK;
 }
 
 extern "C" int pc_fill_shard_dev(pc_ctx* c, int metric, int as_distance, void* shard_dev, void* stream, pc_stats* stats) {
     if (!c || !c->uploaded) { pc_set_error("pc_fill_shard_dev: upload first"); return PC_ERR_STATE; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
     hipStream_t st = (hipStream_t)stream;
     if (c->shard_stride > c->shard_pairs)
         PC_HIP(hipMemsetAsync((double*)shard_dev + c->shard_pairs, 0, (c->shard_stride - c->shard_pairs) * 8, st));
@@ -672,7 +732,7 @@ extern "C" int pc_fill_shard_dev(pc_ctx* c, int metric, int as_distance, void* s
 extern "C" int pc_assemble_dev(pc_ctx* c, const void* gathered_dev, int world, void* out_condensed_dev, void* stream) {
     if (!c || !c->uploaded) { pc_set_error("pc_assemble_dev: upload first"); return PC_ERR_STATE; }
     if (world != c->world) { pc_set_error("pc_assemble_dev: world %d != shard world %d", world, c->world); return PC_ERR_ARG; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
     if (c->balanced)
         return pc_launch_assemble_table((const double*)gathered_dev, c->shard_stride, c->dev.N, c->b_t_rank.as<int32_t>(), c->b_t_lbase.as<int64_t>(),
                                         (double*)out_condensed_dev, (hipStream_t)stream);
@@ -686,7 +746,8 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
     if (n < 0 || (n > 0 && (!a_gene || !b_gene || !n_ident || !n_diag))) { pc_set_error("pc_align_pairs: NULL argument"); return PC_ERR_ARG; }
     if (n == 0) return PC_OK;
     if (n >= 0x7fffffffLL) { pc_set_error("pc_align_pairs: too many pairs"); return PC_ERR_LIMIT; }
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = wait_last_fill(c, nullptr, false); if (rc != PC_OK) return rc;
     const int G = c->dev.G;
     const int nvar = pc_nw_num_variants();
     int forced = -2;                                   // -2: automatic
@@ -782,7 +843,8 @@ extern "C" int pc_get_tie_rule(const pc_ctx* c) { return c ? c->tie_rule : -1; }
 extern "C" int pc_round6_probe(pc_ctx* c, const double* in, double* out, int64_t n) {
     if (!c || n < 0) { pc_set_error("pc_round6_probe: bad argument"); return PC_ERR_ARG; }
     if (n == 0) return PC_OK;
-    int rc = set_device(c); if (rc != PC_OK) return rc;
+    PC_ON_DEVICE(c);
+    int rc = PC_OK;
     DevBuf a, b;
     if ((rc = a.ensure(n * 8)) || (rc = b.ensure(n * 8))) { a.release(); b.release(); return rc; }
     hipError_t e = hipMemcpyAsync(a.p, in, n * 8, hipMemcpyHostToDevice, c->stream);

@@ -57,6 +57,8 @@ typedef struct {
     char* pham_names; int64_t* pham_name_off;    /* pham names joined, [P+1] offsets   */
     char* file;                                  /* the file image the strings point into */
     char error[256];
+    int64_t* gene_order;                         /* [G] line rank of packed gene k in the input: what restores a genome's
+                                                    own (insertion) order of phams and paralogs (genome.py:31-49) */
 } pcp_data;
 
 static int cmp_str(const str_t* a, const str_t* b) {
@@ -78,7 +80,7 @@ static int cmp_gene(const void* x, const void* y) {
 void pcp_free(pcp_data* d) {
     if (!d) return;
     free(d->bitmap); free(d->nph); free(d->ngen); free(d->tlen); free(d->gene_off); free(d->gene_pham); free(d->seq_off);
-    free(d->residues); free(d->names); free(d->name_off); free(d->pham_names); free(d->pham_name_off); free(d->file); free(d);
+    free(d->residues); free(d->names); free(d->name_off); free(d->pham_names); free(d->pham_name_off); free(d->file); free(d->gene_order); free(d);
 }
 
 static pcp_data* fail(pcp_data* d, const char* msg, int64_t line) {
@@ -150,13 +152,14 @@ pcp_data* pcp_load_tsv(const char* path) {
     d->nph = (int32_t*)calloc((size_t)N, sizeof(int32_t)); d->ngen = (int32_t*)calloc((size_t)N, sizeof(int32_t));
     d->tlen = (int64_t*)calloc((size_t)N, sizeof(int64_t)); d->gene_off = (int64_t*)calloc((size_t)N + 1, sizeof(int64_t));
     d->gene_pham = (int32_t*)malloc((size_t)(ng ? ng : 1) * sizeof(int32_t)); d->seq_off = (int64_t*)calloc((size_t)ng + 1, sizeof(int64_t));
+    d->gene_order = (int64_t*)malloc((size_t)(ng ? ng : 1) * sizeof(int64_t));
     int64_t R = 0;
     for (int64_t k = 0; k < ng; ++k) R += genes[k].seq.len;
     d->n_residues = R; d->residues = (uint8_t*)malloc((size_t)(R ? R : 1));
     int64_t r = 0;
     for (int64_t k = 0; k < ng; ++k) {
         const gene_t* ge = &genes[k];
-        d->gene_pham[k] = ge->pham; d->seq_off[k] = r;
+        d->gene_pham[k] = ge->pham; d->seq_off[k] = r; d->gene_order[k] = ge->order;
         for (int32_t i = 0; i < ge->seq.len; ++i) {
             const unsigned char ch = (unsigned char)ge->seq.p[i];
             if (ch >= 0x80) { free(genes); free(gnames); free(pnames); free(gorder); free(grank); free(porder); free(prank);
@@ -181,6 +184,62 @@ pcp_data* pcp_load_tsv(const char* path) {
     for (int32_t i = 0; i < P; ++i) memcpy(d->pham_names + d->pham_name_off[i], pnames[porder[i]].p, (size_t)pnames[porder[i]].len);
     free(genes); free(gnames); free(pnames); free(gorder); free(grank); free(porder); free(prank);
     return d;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * FASTA text of genome g, byte for byte what the reference's Genome.__str__ builds (genome.py:192-199): phams in
+ * the order the genome first met them, paralogs in input order, one record per gene:
+ *   >name=<genome>|pham=<pham>|n=<1-based index among the paralogs>\n<translation>\n
+ * This text is what the pipeline hashes into its cache-directory name (scripts/phamclust.py:86-106) and stashes
+ * under 01_genomes/, so the loader can serve both without materialising a Python object per gene.
+ * Returns the byte count; writes only when `cap` is large enough (call with cap = 0 to size the buffer).
+ * ------------------------------------------------------------------------------------- */
+typedef struct { int64_t first_order; int64_t begin, end; } pham_run_t;
+static int cmp_run(const void* x, const void* y) {
+    const pham_run_t* a = (const pham_run_t*)x; const pham_run_t* b = (const pham_run_t*)y;
+    return (a->first_order > b->first_order) - (a->first_order < b->first_order);
+}
+static int64_t put_dec(char* p, int64_t v) {
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (int i = 0; i < n; ++i) p[i] = tmp[n - 1 - i];
+    return n;
+}
+int64_t pcp_genome_fasta(const pcp_data* d, int32_t g, char* out, int64_t cap) {
+    if (!d || d->status != 0 || g < 0 || g >= d->n_genomes) return -1;
+    const int64_t k0 = d->gene_off[g], k1 = d->gene_off[g + 1];
+    const int64_t name_len = d->name_off[g + 1] - d->name_off[g];
+    const char* name = d->names + d->name_off[g];
+    pham_run_t* runs = (pham_run_t*)malloc((size_t)(k1 - k0 + 1) * sizeof(pham_run_t));
+    if (!runs) return -1;
+    int64_t nr = 0, need = 0;
+    for (int64_t k = k0; k < k1;) {                                    /* genes are sorted by (pham id, input order) */
+        int64_t e = k;
+        while (e < k1 && d->gene_pham[e] == d->gene_pham[k]) ++e;
+        runs[nr].first_order = d->gene_order[k]; runs[nr].begin = k; runs[nr].end = e; ++nr;
+        const int64_t plen = d->pham_name_off[d->gene_pham[k] + 1] - d->pham_name_off[d->gene_pham[k]];
+        for (int64_t j = k; j < e; ++j) need += 6 + name_len + 6 + plen + 3 + 20 + 1 + (d->seq_off[j + 1] - d->seq_off[j]) + 1;
+        k = e;
+    }
+    if (need > cap || !out) { free(runs); return need; }                /* an upper bound (20 digits reserved per index) */
+    qsort(runs, (size_t)nr, sizeof(pham_run_t), cmp_run);
+    char* p = out;
+    for (int64_t r = 0; r < nr; ++r) {
+        const int32_t ph = d->gene_pham[runs[r].begin];
+        const char* pname = d->pham_names + d->pham_name_off[ph];
+        const int64_t plen = d->pham_name_off[ph + 1] - d->pham_name_off[ph];
+        for (int64_t j = runs[r].begin; j < runs[r].end; ++j) {
+            memcpy(p, ">name=", 6); p += 6; memcpy(p, name, (size_t)name_len); p += name_len;
+            memcpy(p, "|pham=", 6); p += 6; memcpy(p, pname, (size_t)plen); p += plen;
+            memcpy(p, "|n=", 3); p += 3; p += put_dec(p, j - runs[r].begin + 1);
+            *p++ = '\n';
+            const int64_t sl = d->seq_off[j + 1] - d->seq_off[j];
+            memcpy(p, d->residues + d->seq_off[j], (size_t)sl); p += sl;
+            *p++ = '\n';
+        }
+    }
+    free(runs);
+    return (int64_t)(p - out);
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -11,6 +11,11 @@ The index arithmetic below mirrors ``apply_shard`` / ``k_assemble`` in csrc (clo
 so that host code and CPU tests can reason about the layout without a GPU.
 """
 
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 
 
@@ -73,10 +78,11 @@ def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True):
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    root = dist.get_global_rank(group, 0) if group is not None else 0      # dist.gather's dst is a GLOBAL rank
     ctx.set_shard(rank, world, balanced=balanced and world > 1)
     stride = ctx.shard_stride()
-    device = torch.device("cuda", torch.cuda.current_device())
-    stream = torch.cuda.current_stream().cuda_stream
+    device = torch.device("cuda", ctx.device_id)                           # buffers live on the context's GPU, whatever
+    stream = torch.cuda.current_stream(device).cuda_stream                 # torch's "current device" happens to be
     shard = torch.empty(max(stride, 1), dtype=torch.float64, device=device)
     stats = ctx.fill_shard_dev(metric, as_distance, shard.data_ptr(), stream)
     if world == 1:
@@ -85,13 +91,129 @@ def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True):
         # rehearsal transport (several ranks sharing one GPU, or no RCCL): same shard / gather / assembly, staged
         # through host memory because gloo gathers CPU tensors only
         host = torch.empty(world * max(stride, 1), dtype=torch.float64) if rank == 0 else None
-        dist.gather(shard.cpu(), list(host.chunk(world)) if rank == 0 else None, dst=0, group=group)
+        dist.gather(shard.cpu(), list(host.chunk(world)) if rank == 0 else None, dst=root, group=group)
         gathered = host.to(device) if rank == 0 else None
     else:
         gathered = torch.empty(world * max(stride, 1), dtype=torch.float64, device=device) if rank == 0 else None
-        dist.gather(shard, list(gathered.chunk(world)) if rank == 0 else None, dst=0, group=group)
+        dist.gather(shard, list(gathered.chunk(world)) if rank == 0 else None, dst=root, group=group)
     if rank != 0:
         return None, stats
     out = torch.empty(max(ctx.n_pairs, 1), dtype=torch.float64, device=device)
     ctx.assemble_dev(gathered.data_ptr(), world, out.data_ptr(), stream)
     return out[:ctx.n_pairs], stats
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The product route: matrix_de_novo / the CLI under `torch.distributed.run` (one process per GPU).
+# The reference parallelises inside matrix_de_novo through its `cpus` argument (matrix.py:432,471-472; flag -t,
+# cli.py:113-115); here the same call shards over the ranks of the job it is running in.
+# ---------------------------------------------------------------------------------------------------------
+def env_world():
+    """(rank, local_rank, world) as the launcher exported them; (0, 0, 1) outside a launcher."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def backend_name():
+    """"nccl" (= RCCL over xGMI) unless PHAMCLUST_DIST_BACKEND says otherwise ("gloo": rehearsal transport for a box
+    with fewer GPUs than ranks -- ranks share devices and the gather is staged through host memory)."""
+    return os.environ.get("PHAMCLUST_DIST_BACKEND", "nccl")
+
+
+def local_device():
+    """HIP device ordinal of this rank: LOCAL_RANK; under the gloo rehearsal LOCAL_RANK modulo the devices present."""
+    import torch
+    _, local_rank, _ = env_world()
+    if backend_name() != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    return int(os.environ.get("PHAMCLUST_DEVICE", local_rank))
+
+
+def ensure_process_group():
+    """Join the job's process group if the launcher started more than one rank and nothing has joined it yet.
+    Must run before this process's first GPU call under nccl (RCCL binds the device at init).  Returns (rank, world)."""
+    import torch
+    import torch.distributed as dist
+    rank, _, world = env_world()
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        device = local_device()
+        torch.cuda.set_device(device)
+        if backend_name() == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend_name())
+    return dist.get_rank(), dist.get_world_size()
+
+
+def broadcast_flag(value, src=0):
+    """One small control-plane broadcast (e.g. "rank 0 found a cached matrix, nobody fills")."""
+    import torch.distributed as dist
+    box = [bool(value)]
+    dist.broadcast_object_list(box, src=src)
+    return bool(box[0])
+
+
+def fill_condensed(ctx, metric, as_distance=True):
+    """Sharded fill of the uploaded genomes over the job's ranks.  Rank 0 gets the host condensed vector and the
+    stats of its shard; every other rank gets (None, stats)."""
+    import torch
+    out, stats = fill_distributed(ctx, metric, as_distance)
+    if out is None:
+        return None, stats
+    host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+    host.copy_(out, non_blocking=False)
+    return host.numpy(), stats
+
+
+def balanced_deal(costs, world, pair_floor=2000):
+    """Host mirror of pc_set_shard_balanced (csrc/pc_api.hip): target t costs ``costs[t] + t * pair_floor`` (its DP
+    cells plus a floor per pair); targets go, heaviest first (ties: lower index), to the rank with the least work so
+    far (ties: lowest rank).  Returns (t_rank[N], t_lbase[N], stride): pair (s, t) lives at
+    gathered[t_rank[t] * stride + t_lbase[t] + s]."""
+    costs = np.asarray(costs, dtype=np.uint64)
+    n = costs.shape[0]
+    total = costs + np.arange(n, dtype=np.uint64) * np.uint64(pair_floor)
+    order = sorted(range(n), key=lambda t: (-int(total[t]), t))
+    load = [0] * world
+    t_rank = np.zeros(n, dtype=np.int32)
+    for t in order:
+        best = min(range(world), key=lambda r: (load[r], r))
+        t_rank[t] = best
+        load[best] += int(total[t])
+    t_lbase = np.zeros(n, dtype=np.int64)
+    fill = [0] * world
+    for t in range(n):
+        t_lbase[t] = fill[t_rank[t]]
+        fill[t_rank[t]] += t
+    return t_rank, t_lbase, max(fill) if n else 0
+
+
+def assemble_table_host(gathered, n_genomes, t_rank, t_lbase):
+    """numpy mirror of k_assemble_table: gathered[world, stride] + the deal's tables -> condensed vector."""
+    gathered = np.asarray(gathered)
+    out = np.empty(n_genomes * (n_genomes - 1) // 2, dtype=gathered.dtype)
+    for t in range(1, n_genomes):
+        s = np.arange(t, dtype=np.int64)
+        out[condensed_index(n_genomes, s, t)] = gathered[int(t_rank[t]), int(t_lbase[t]):int(t_lbase[t]) + t]
+    return out
+
+
+def free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n_ranks, module, argv, env=None):
+    """Start ``python -m torch.distributed.run --nproc-per-node n_ranks -m <module> <argv>`` as a CHILD process and
+    return its exit code.  Called before this process has touched the GPU (the CLI's ``--gpus N``): the children, not
+    this process, own the devices."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "-m", module] + list(argv)
+    child_env = dict(os.environ)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child_env.update(env or {})
+    return subprocess.call(cmd, env=child_env)

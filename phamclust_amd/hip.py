@@ -43,7 +43,7 @@ class PcStats(ctypes.Structure):
 
 EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
-           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule"]
+           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs"]
 
 _lib = None
 
@@ -88,6 +88,8 @@ def load():
     L.pc_round6_probe.argtypes = [vp, _f64p, _f64p, ctypes.c_int64]
     L.pc_last_align_ms.argtypes = [vp]
     L.pc_last_align_ms.restype = ctypes.c_float
+    L.pc_shard_table.argtypes = [vp, _i32p, _i64p]
+    L.pc_target_costs.argtypes = [vp, _u64p]
     L.pc_set_tie_rule.argtypes = [vp, ctypes.c_int]
     L.pc_get_tie_rule.argtypes = [vp]
     _lib = L
@@ -105,6 +107,7 @@ class Context:
         self._lib = load()
         self._h = ctypes.c_void_p()
         self._packed = None
+        self.device_id = int(device_id)
         self._check(self._lib.pc_ctx_create(ctypes.byref(self._h), int(device_id)))
 
     def _check(self, rc):
@@ -156,6 +159,19 @@ class Context:
             call = self._lib.pc_set_shard_balanced if balanced else self._lib.pc_set_shard
             self._check(call(self._h, int(rank), int(world)))
             self._shard = key
+
+    def shard_table(self):
+        """(t_rank[N], t_lbase[N]) of the deal in force: pair (s, t) is element t_lbase[t] + s of rank t_rank[t]'s shard."""
+        t_rank = np.zeros(self.n_genomes, dtype=np.int32)
+        t_lbase = np.zeros(self.n_genomes, dtype=np.int64)
+        self._check(self._lib.pc_shard_table(self._h, _ptr(t_rank, _i32p), _ptr(t_lbase, _i64p)))
+        return t_rank, t_lbase
+
+    def target_costs(self):
+        """DP cells behind every target genome (available once a cost-balanced deal has been computed)."""
+        cost = np.zeros(self.n_genomes, dtype=np.uint64)
+        self._check(self._lib.pc_target_costs(self._h, _ptr(cost, _u64p)))
+        return cost
 
     def shard_pairs(self):
         return int(self._lib.pc_shard_pairs(self._h))

@@ -40,18 +40,22 @@ class SymMatrix:
     def from_condensed(cls, nodes, condensed, is_distance=True):
         """Build from a scipy-condensed vector whose values are already rounded to 6 places;
         the diagonal is preset to ``1.0 - is_distance`` as matrix_de_novo does (matrix.py:467-468)."""
-        self = cls(list(nodes), is_distance=is_distance)
-        n = len(self._nodes)
-        condensed = np.asarray(condensed, dtype=np.float64)
+        nodes = list(nodes)
+        n = len(nodes)
+        condensed = np.ascontiguousarray(condensed, dtype=np.float64)
         if condensed.shape != (n * (n - 1) // 2,):
             raise ValueError(f"need {n * (n - 1) // 2} condensed values but got {condensed.shape}")
         if condensed.size and not (np.nanmin(condensed) >= 0.0 and np.nanmax(condensed) <= 1.0):
             raise ValueError("weight not in [0.0, 1.0]")
-        if n > 1:
-            iu = np.triu_indices(n, k=1)
-            self._data[iu] = condensed
-            self._data[(iu[1], iu[0])] = condensed
-        np.fill_diagonal(self._data, 0.0 if is_distance else 1.0)
+        self = cls.__new__(cls)
+        self._nodes = nodes
+        self._slot = {name: k for k, name in enumerate(nodes)}
+        # scipy expands the vector in C: no N^2/2 index arrays (two of them were 800 MB at N = 10,000)
+        self._data = squareform(condensed, force="tomatrix", checks=False) if n > 1 else np.zeros((n, n), dtype=np.float64)
+        self._is_distance = is_distance
+        self._locked = False
+        if not is_distance:
+            np.fill_diagonal(self._data, 1.0)
         return self
 
     # -- properties ------------------------------------------------------------------
@@ -67,7 +71,11 @@ class SymMatrix:
         return np.fromiter((self._slot[name] for name in self._nodes), dtype=np.int64, count=len(self._nodes))
 
     def _ordered(self):
+        """The weights in current node order.  READ-ONLY for callers: when the traversal order is still the storage
+        order this is the storage itself, not a copy (an N = 10,000 matrix is 800 MB)."""
         order = self._order()
+        if order.size == self._data.shape[0] and (order == np.arange(order.size)).all():
+            return self._data
         return self._data[np.ix_(order, order)]
 
     @property
@@ -77,22 +85,21 @@ class SymMatrix:
         n = len(self)
         if n < 2:
             return 0.0
-        off = self._ordered()[np.triu_indices(n, k=1)]
+        off = squareform(self._ordered(), force="tovector", checks=False)
         top = np.nanmax(off) if off.size else 0.0
         return round(float(max(top, 0.0)), 6)
 
     def _central(self):
-        """Per node, the mean of its N+1 incident weights (diagonal twice), summed in the
-        reference's order (matrix.py:84-97) so that ties fall the same way."""
+        """Per node, the mean of its N+1 incident weights.  The reference gathers them by walking the upper half
+        (matrix.py:84-97), so node k's list reads w(0,k) .. w(k-1,k), w(k,k) TWICE, w(k,k+1) .. and is summed left
+        to right; sweeping the columns in order and adding the diagonal a second time right after its own column
+        adds the same numbers in the same order for every node at once (ties between nodes fall as they do there)."""
         n = len(self)
         m = self._ordered()
-        wide = np.empty((n, n + 1), dtype=np.float64)
-        rows = np.arange(n)
-        for k in range(n):                       # row k: w(0..k, k), w(k,k) again, w(k, k+1..)
-            wide[k, :k + 1] = m[k, :k + 1]
-            wide[k, k + 1] = m[k, k]
-            wide[k, k + 2:] = m[k, k + 1:]
-        totals = np.add.accumulate(wide, axis=1)[rows, -1]
+        totals = np.zeros(n, dtype=np.float64)
+        for j in range(n):
+            totals += m[j]                       # column j == row j (symmetric); contiguous
+            totals[j] += m[j, j]
         return [(name, float(total) / (n + 1)) for name, total in zip(self._nodes, totals)]
 
     @property
@@ -110,8 +117,7 @@ class SymMatrix:
         if len(self) == 1:
             node = self._nodes[0]
             return self.get_weight(node, node), 0.0, 0.0
-        n = len(self)
-        edges = self._ordered()[np.triu_indices(n, k=1)].tolist()
+        edges = squareform(self._ordered(), force="tovector", checks=False).tolist()    # upper half, row by row
         mean = average(edges)
         std_dev = standard_deviation(edges, mean)
         skew = 0.0 if std_dev == 0.0 else skewness(edges, mean)
@@ -128,28 +134,41 @@ class SymMatrix:
         return sub
 
     def append_node(self, source, data):
+        """Grow by one node whose weights to every node (itself included) come in ``data`` (matrix.py:169-213):
+        the new name must be new, ``data`` must cover exactly the current nodes plus the new one, and the self-edge
+        must be what the diagonal of this kind of matrix holds."""
+        if self._locked:
+            raise AttributeError("matrix is marked as read-only")
         if source in self:
             raise KeyError(f"node '{source}' is already in this matrix")
         if source not in data:
             raise KeyError(f"incoming data lacks an self-edge for '{source}'")
-        if self.is_distance and data[source] != 0.0:
-            raise ValueError(f"nonsense value {data[source]} for self-edge on distance matrix")
-        if not self.is_distance and data[source] != 1.0:
-            raise ValueError(f"nonsense value {data[source]} for self-edge on similarity matrix")
-        missed = set(self._slot) - data.keys()
-        if missed:
-            raise KeyError(f"missing edge(s) for {source} vs: {missed}")
-        extra = set(data.keys()) - {source} - set(self._slot)
-        if extra:
-            raise KeyError(f"specified edges for nodes not found in matrix: {extra}")
+        on_diagonal = 0.0 if self.is_distance else 1.0
+        if data[source] != on_diagonal:
+            kind = "distance" if self.is_distance else "similarity"
+            raise ValueError(f"nonsense value {data[source]} for self-edge on {kind} matrix")
+        given = set(data) - {source}
+        absent = set(self._slot) - given
+        if absent:
+            raise KeyError(f"missing edge(s) for {source} vs: {absent}")
+        unknown = given - set(self._slot)
+        if unknown:
+            raise KeyError(f"specified edges for nodes not found in matrix: {unknown}")
         n = self._data.shape[0]
-        grown = np.full((n + 1, n + 1), np.nan, dtype=np.float64)
+        edge = np.empty(n + 1, dtype=np.float64)
+        for name, k in self._slot.items():
+            edge[k] = data[name]
+        edge[n] = data[source]
+        if not (edge.min() >= 0.0 and edge.max() <= 1.0):
+            raise ValueError(f"weight {edge[(edge < 0.0) | (edge > 1.0) | (edge != edge)][0]} not in [0.0, 1.0]")
+        edge = np.array([round(float(w), 6) for w in edge])     # Python's round: what set_weight stores (matrix.py:323)
+        grown = np.empty((n + 1, n + 1), dtype=np.float64)
         grown[:n, :n] = self._data
+        grown[n, :] = edge
+        grown[:, n] = edge
         self._data = grown
         self._slot[source] = n
         self._nodes.append(source)
-        for target in self._nodes:
-            self.set_weight(source, target, data[target])
 
     def get_weight(self, source, target):
         if source not in self:
@@ -182,25 +201,31 @@ class SymMatrix:
         return self
 
     def reorder(self, nodes=None):
-        if not nodes:
-            nodes = [self._nodes[x] for x in _get_tree_order(self)]
-        if len(nodes) != len(self):
-            raise ValueError(f"need {len(self)} nodes but got {len(nodes)}")
-        for node in nodes:
-            if node not in self:
-                raise KeyError(f"node '{node}' not in matrix")
-        self._nodes = nodes
+        """New traversal order (storage stays put); without ``nodes``: leaf order of the single-linkage tree
+        (matrix.py:249-263)."""
+        order = list(nodes) if nodes else [self._nodes[leaf] for leaf in _get_tree_order(self)]
+        if len(order) != len(self._nodes):
+            raise ValueError(f"need {len(self)} nodes but got {len(order)}")
+        stranger = next((name for name in order if name not in self), None)
+        if stranger is not None:
+            raise KeyError(f"node '{stranger}' not in matrix")
+        self._nodes = order
 
     def nearest_neighbors(self, source, threshold):
-        is_distance = self.is_distance
-        neighbors = []
-        for target in self._nodes:
-            if source == target:
-                continue
-            weight = self.get_weight(source, target)
-            if (is_distance and weight <= threshold) or (not is_distance and weight >= threshold):
-                neighbors.append(target)
-        return sorted(neighbors, reverse=not is_distance, key=lambda x: self.get_weight(source, x))
+        """Nodes within ``threshold`` of ``source`` (<= on distances, >= on similarities), closest first; equally
+        close ones keep their traversal order (matrix.py:265-296: a stable sort, reversed for similarities)."""
+        order = self._order()
+        if order.size == 0 or (order.size == 1 and self._nodes[0] == source):
+            return []
+        if source not in self:
+            raise KeyError(f"node '{source}' not in matrix")
+        row = self._data[self._slot[source], order]
+        others = order != self._slot[source]
+        if np.isnan(row[others]).any():
+            raise TypeError("cannot rank neighbours of a node with unset edges")
+        near = np.flatnonzero(others & ((row <= threshold) if self.is_distance else (row >= threshold)))
+        ranked = near[np.argsort(row[near] if self.is_distance else -row[near], kind="stable")]
+        return [self._nodes[k] for k in ranked]
 
     def lock(self):
         self._locked = True
@@ -215,7 +240,7 @@ class SymMatrix:
         full = self._ordered()
         if condensed:
             return squareform(full, force="tovector")
-        return full
+        return full.copy() if full is self._data else full
 
     # -- container protocol ------------------------------------------------------------
     def __contains__(self, item):
@@ -281,6 +306,10 @@ _CONTEXTS = {}
 
 
 def default_device():
+    """PHAMCLUST_DEVICE, else this rank's LOCAL_RANK (one process per GPU under torch.distributed.run), else 0."""
+    if "PHAMCLUST_DEVICE" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from phamclust_amd import distributed
+        return distributed.local_device()
     return int(os.environ.get("PHAMCLUST_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
@@ -298,21 +327,52 @@ def _metric_name(func):
     return metrics.ACCELERATED.get(func)
 
 
+LAST_FILL = {}          # what the last accelerated matrix_de_novo did: the pipeline's log line reads it
+
+
+def _packed_of(genomes):
+    """The packed form of ``genomes``: the loader's own arrays when the list is exactly what the C loader produced
+    (pack.load_tsv_genomes: untouched lazy genomes, all of them, in order), else a fresh pack of the objects."""
+    from phamclust_amd.pack import pack_genomes, packed_behind
+    return packed_behind(genomes) or pack_genomes(genomes)
+
+
 def matrix_de_novo(genomes, func, cpus, as_distance=True):
     """Fill an N x N ``SymMatrix`` with ``func`` over every genome pair (matrix.py:432-497).
 
-    ``cpus`` is accepted for signature compatibility; the six METRICS run on the GPU.
+    The six METRICS run on the GPU.  Where the reference spreads the pairs over ``cpus`` worker processes
+    (matrix.py:471-472), this spreads them over the GPUs of the job it runs in: under
+    ``python -m torch.distributed.run --nproc-per-node N`` (one process per GPU; ``phamclust --gpus N`` starts that
+    for you) every rank calls this with the same genomes, fills its static shard of the pair list, and ONE gather
+    brings the shards to rank 0.  Rank 0 returns the matrix; every other rank returns ``None``.  ``cpus`` itself is
+    accepted for signature compatibility only.
     """
     if len(genomes) == 0:
         raise ValueError("need at least 1 genome to construct matrix de novo")
     names = [g.name for g in genomes]
     metric = _metric_name(func)
     if metric is not None:
-        from phamclust_amd.pack import pack_genomes
+        import time
+        from phamclust_amd import distributed
+        rank, world = distributed.ensure_process_group()          # before the first GPU call of this process
+        t0 = time.perf_counter()
+        packed = _packed_of(genomes)
+        t1 = time.perf_counter()
         ctx = get_context()
-        ctx.upload(pack_genomes(genomes))
-        condensed, stats = ctx.fill(metric, as_distance=as_distance, want_stats=True)
-        logging.debug(f"{len(genomes)} genomes -> {condensed.size} edges on device in {stats['ms_total']:.3f} ms")
+        ctx.upload(packed)
+        t2 = time.perf_counter()
+        if world > 1:
+            condensed, stats = distributed.fill_condensed(ctx, metric, as_distance)
+        else:
+            condensed, stats = ctx.fill(metric, as_distance=as_distance, want_stats=True)
+        t3 = time.perf_counter()
+        LAST_FILL.clear()
+        LAST_FILL.update(stats, metric=metric, n_genomes=len(genomes), genome_pairs=packed.n_pairs, n_gpus=world, rank=rank,
+                         pack_s=t1 - t0, upload_s=t2 - t1, fill_s=t3 - t2)
+        logging.debug(f"{len(genomes)} genomes -> {packed.n_pairs} edges on {world} device(s): pack {t1 - t0:.3f} s, "
+                      f"upload {t2 - t1:.3f} s, fill+gather+D2H {t3 - t2:.3f} s (kernels {stats['ms_total']:.3f} ms on this rank)")
+        if condensed is None:
+            return None
         return SymMatrix.from_condensed(names, condensed, is_distance=as_distance)
 
     # any other callable: the reference's per-pair semantics, in its batch order

@@ -23,6 +23,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+from phamclust_amd.genome import Genome
+
 
 @dataclass
 class PackedGenomes:
@@ -39,6 +41,7 @@ class PackedGenomes:
     gene_pham: np.ndarray
     seq_off: np.ndarray
     residues: np.ndarray
+    gene_order: np.ndarray = None              # C loader only: input-line rank of each gene (restores insertion order)
     _keepalive: list = field(default_factory=list, repr=False)
 
     @property
@@ -123,7 +126,6 @@ def pack_genomes(genomes):
 
 def unpack_genomes(packed):
     """Inverse of :func:`pack_genomes` (used by the synthetic generator and tests)."""
-    from phamclust_amd.genome import Genome
     genomes = []
     res = packed.residues.tobytes()
     for g_idx, name in enumerate(packed.names):
@@ -138,12 +140,15 @@ def unpack_genomes(packed):
 # ---------------------------------------------------------------------------------------
 # TSV -> PackedGenomes in C (csrc/pc_pack.c): no Python object per gene
 # ---------------------------------------------------------------------------------------
-def load_tsv_packed(filepath):
-    """Parse the reference's 2/3-column TSV (scripts/phamclust.py:21-47) straight into packed form,
-    genomes sorted by name (scripts/phamclust.py:221).  Equals pack_genomes(sorted(load_genomes_from_tsv))."""
+_PACK_LIB = None
+
+
+def _pack_lib():
     import ctypes
     import os
-
+    global _PACK_LIB
+    if _PACK_LIB is not None:
+        return _PACK_LIB
     lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpc_pack.so")
     if not os.path.exists(lib_path):
         raise RuntimeError(f"{lib_path} is missing - run `python -m phamclust_amd.build` first")
@@ -158,34 +163,152 @@ def load_tsv_packed(filepath):
                     ("seq_off", ctypes.POINTER(ctypes.c_int64)), ("residues", ctypes.POINTER(ctypes.c_uint8)),
                     ("names", ctypes.POINTER(ctypes.c_char)), ("name_off", ctypes.POINTER(ctypes.c_int64)),
                     ("pham_names", ctypes.POINTER(ctypes.c_char)), ("pham_name_off", ctypes.POINTER(ctypes.c_int64)),
-                    ("file", ctypes.c_void_p), ("error", ctypes.c_char * 256)]
+                    ("file", ctypes.c_void_p), ("error", ctypes.c_char * 256),
+                    ("gene_order", ctypes.POINTER(ctypes.c_int64))]
 
     lib = ctypes.CDLL(lib_path)
     lib.pcp_load_tsv.restype = ctypes.POINTER(_Data)
     lib.pcp_load_tsv.argtypes = [ctypes.c_char_p]
     lib.pcp_free.argtypes = [ctypes.POINTER(_Data)]
+    lib.pcp_genome_fasta.restype = ctypes.c_int64
+    lib.pcp_genome_fasta.argtypes = [ctypes.POINTER(_Data), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64]
+    _PACK_LIB = lib
+    return lib
+
+
+class _LoaderHandle:
+    """Owns the C loader's result for as long as lazy genomes may ask it for their FASTA text."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def fasta(self, index):
+        import ctypes
+        need = self.lib.pcp_genome_fasta(self.handle, index, None, 0)
+        if need < 0:
+            raise RuntimeError("pcp_genome_fasta failed")
+        buf = ctypes.create_string_buffer(int(need) + 1)
+        size = self.lib.pcp_genome_fasta(self.handle, index, buf, need + 1)
+        return buf.raw[:size]
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pcp_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _load_tsv(filepath, keep_handle):
+    import ctypes
+    import os
+    lib = _pack_lib()
     handle = lib.pcp_load_tsv(os.fsencode(str(filepath)))
     if not handle:
         raise MemoryError("pcp_load_tsv: out of memory")
-    try:
-        d = handle.contents
-        if d.status != 0:
-            raise ValueError(d.error.decode("utf-8", "replace"))
-        N, P, W, G, R = d.n_genomes, d.n_phams, d.words_per_row, d.n_genes, d.n_residues
+    owner = _LoaderHandle(lib, handle)
+    d = handle.contents
+    if d.status != 0:
+        raise ValueError(d.error.decode("utf-8", "replace"))
+    N, P, W, G, R = d.n_genomes, d.n_phams, d.words_per_row, d.n_genes, d.n_residues
 
-        def arr(ptr, n):
-            return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+    def arr(ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
 
-        def strings(buf, offs, n, nbytes):
-            raw = ctypes.string_at(buf, nbytes)
-            off = np.ctypeslib.as_array(offs, shape=(n + 1,))
-            return [raw[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(n)]
+    def strings(buf, offs, n, nbytes):
+        raw = ctypes.string_at(buf, nbytes)
+        off = np.ctypeslib.as_array(offs, shape=(n + 1,))
+        return [raw[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(n)]
 
-        return PackedGenomes(
-            names=strings(d.names, d.name_off, N, d.names_bytes),
-            pham_names=strings(d.pham_names, d.pham_name_off, P, d.pham_names_bytes),
-            n_genomes=N, n_phams=P, words_per_row=W, bitmap=arr(d.bitmap, N * W), nph=arr(d.nph, N), ngen=arr(d.ngen, N),
-            tlen=arr(d.tlen, N), gene_off=arr(d.gene_off, N + 1), gene_pham=arr(d.gene_pham, G), seq_off=arr(d.seq_off, G + 1),
-            residues=arr(d.residues, R)).validate()
-    finally:
-        lib.pcp_free(handle)
+    packed = PackedGenomes(
+        names=strings(d.names, d.name_off, N, d.names_bytes),
+        pham_names=strings(d.pham_names, d.pham_name_off, P, d.pham_names_bytes),
+        n_genomes=N, n_phams=P, words_per_row=W, bitmap=arr(d.bitmap, N * W), nph=arr(d.nph, N), ngen=arr(d.ngen, N),
+        tlen=arr(d.tlen, N), gene_off=arr(d.gene_off, N + 1), gene_pham=arr(d.gene_pham, G), seq_off=arr(d.seq_off, G + 1),
+        residues=arr(d.residues, R)).validate()
+    if keep_handle:
+        packed.gene_order = arr(d.gene_order, G)
+        packed._keepalive.append(owner)
+    return packed, owner
+
+
+def load_tsv_packed(filepath):
+    """Parse the reference's 2/3-column TSV (scripts/phamclust.py:21-47) straight into packed form,
+    genomes sorted by name (scripts/phamclust.py:221).  Equals pack_genomes(sorted(load_genomes_from_tsv))."""
+    return _load_tsv(filepath, keep_handle=False)[0]
+
+
+class LazyGenome(Genome):
+    """A ``Genome`` whose genes still live in the loader's packed arrays.  ``phams`` (pham -> translations, in the
+    genome's own insertion order) is built on first use; the FASTA text -- what the pipeline hashes and stashes --
+    comes straight from the loader.  Touching ``phams`` detaches the object from the packed form (it may have been
+    edited), after which it behaves like any other ``Genome``."""
+
+    def __init__(self, name, packed, owner, index):
+        self.name = name
+        self._packed, self._owner, self._index = packed, owner, index
+        self._phams = None
+
+    @property
+    def phams(self):
+        if self._phams is None:
+            pk, g = self._packed, self._index
+            k0, k1 = int(pk.gene_off[g]), int(pk.gene_off[g + 1])
+            genes = sorted(range(k0, k1), key=lambda k: int(pk.gene_order[k]))
+            text = pk.residues[int(pk.seq_off[k0]):int(pk.seq_off[k1])].tobytes().decode("latin-1")
+            base = int(pk.seq_off[k0])
+            found = {}
+            for k in genes:
+                found.setdefault(pk.pham_names[int(pk.gene_pham[k])], []).append(
+                    text[int(pk.seq_off[k]) - base:int(pk.seq_off[k + 1]) - base])
+            self._phams = found
+        return self._phams
+
+    @phams.setter
+    def phams(self, value):
+        self._phams = value
+
+    def is_packed(self):
+        return self._phams is None
+
+    def fasta_bytes(self):
+        if self._phams is None:
+            return self._owner.fasta(self._index)
+        return super().__str__().encode()
+
+    def __str__(self):
+        return self.fasta_bytes().decode() if self._phams is None else super().__str__()
+
+    __repr__ = __str__
+
+    def __len__(self):
+        return int(self._packed.ngen[self._index]) if self._phams is None else super().__len__()
+
+    def save(self, filepath):
+        with open(filepath, "wb") as handle:
+            handle.write(self.fasta_bytes())
+        return filepath
+
+
+def load_tsv_genomes(filepath):
+    """The pipeline's loader: ``list[Genome]`` sorted by name, as scripts/phamclust.py:21-47,221 leave it, but the
+    parsing, sorting, pham vocabulary, bitmap and residue packing are one pass of C (csrc/pc_pack.c), and the
+    genomes are lazy views of that result -- ``matrix_de_novo`` uploads the packed arrays as they are."""
+    packed, owner = _load_tsv(filepath, keep_handle=True)
+    return [LazyGenome(name, packed, owner, k) for k, name in enumerate(packed.names)]
+
+
+def packed_behind(genomes):
+    """The loader's PackedGenomes if ``genomes`` is exactly its full, ordered, untouched list of lazy genomes."""
+    first = genomes[0] if len(genomes) else None
+    if not isinstance(first, LazyGenome):
+        return None
+    packed = first._packed
+    if len(genomes) != packed.n_genomes:
+        return None
+    for k, genome in enumerate(genomes):
+        if not isinstance(genome, LazyGenome) or genome._packed is not packed or genome._index != k or not genome.is_packed() \
+                or genome.name != packed.names[k]:
+            return None
+    return packed

@@ -18,11 +18,14 @@ import time
 
 import numpy as np
 
+from phamclust_amd import distributed
+from phamclust_amd import matrix as _matrix
 from phamclust_amd.cli import METRICS, parse_args
 from phamclust_amd.clustering import hierarchical_clustering
 from phamclust_amd.genome import Genome
 from phamclust_amd.heatmap import CSS_COLORS, draw_heatmap
 from phamclust_amd.matrix import matrix_de_novo, matrix_from_squareform, matrix_to_adjacency, matrix_to_squareform
+from phamclust_amd.pack import load_tsv_genomes
 
 LOG_STR_FMT = "phamclust: %(asctime)s.%(msecs)03d: %(levelname)s: %(message)s"
 LOG_TIME_FMT = "%H:%M:%S"
@@ -63,11 +66,23 @@ def load_genomes_from_fasta_dir(filepath):
     return list(found.values())
 
 
+def load_genomes(filepath):
+    """TSV -> name-sorted genomes through the C loader (csrc/pc_pack.c): same genomes, same order, same FASTA text as
+    ``sorted(load_genomes_from_tsv(filepath), key=name)`` (scripts/phamclust.py:21-47, 221), without a Python object
+    per gene.  Translations with bytes outside ASCII take the Python loader."""
+    try:
+        return load_tsv_genomes(filepath)
+    except ValueError as exc:
+        if "non-ASCII" not in str(exc):
+            raise
+        return sorted(load_genomes_from_tsv(filepath), key=lambda g: g.name)
+
+
 def _hash_genomes(genomes):
     """md5 of the concatenated FASTA text, genomes in the order given (the cache key)."""
     md5 = hashlib.md5()
     for genome in genomes:
-        md5.update(str(genome).encode())
+        md5.update(genome.fasta_bytes() if hasattr(genome, "fasta_bytes") else str(genome).encode())
     return md5.hexdigest()
 
 
@@ -84,6 +99,7 @@ class _Run:
     def __init__(self, outdir, metric, colors, midpoint):
         self.outdir, self.metric, self.colors, self.midpoint = outdir, metric, colors, midpoint
         self.genomes, self.by_name, self.cache, self.stage = [], {}, None, None
+        self.rank, self.world = 0, 1          # this process's place in the job (one process per GPU)
 
     @staticmethod
     def _dir(path, fresh=False):
@@ -102,9 +118,15 @@ class _Run:
     # 1
     def read(self, infile, is_genome_dir):
         self.banner(1, "genomes")
-        self.genomes = load_genomes_from_fasta_dir(infile) if is_genome_dir else load_genomes_from_tsv(infile)
-        self.genomes.sort(key=lambda g: g.name)
+        t0 = time.perf_counter()
+        if is_genome_dir:
+            self.genomes = sorted(load_genomes_from_fasta_dir(infile), key=lambda g: g.name)
+        else:
+            self.genomes = load_genomes(infile)
         self.by_name = {g.name: g for g in self.genomes}
+        log.info(f"loaded {len(self.genomes)} genomes in {time.perf_counter() - t0:.3f} s")
+        if self.rank != 0:                    # the other ranks only need the genomes: rank 0 owns the output tree
+            return
         digest = _hash_genomes(self.genomes)
         self.cache = self._dir(self.outdir / f"{digest}.tmp")
         log.info(f"{len(self.genomes)} genomes, md5 {digest}, cache {self.cache.name}")
@@ -117,14 +139,32 @@ class _Run:
     # 2
     def distances(self, cpus):
         self.banner(2, f"{self.metric} distance matrix")
-        cached = self._dir(self.cache / "02_distmats") / f"{self.metric}_distance_matrix.tsv"
+        cached, have_cache = None, False
+        if self.rank == 0:
+            cached = self._dir(self.cache / "02_distmats") / f"{self.metric}_distance_matrix.tsv"
+            have_cache = cached.is_file()
+        if self.world > 1:                    # rank 0 owns the cache; the others learn whether there is work for them
+            have_cache = distributed.broadcast_flag(have_cache, src=0)
         t0 = time.perf_counter()
-        if cached.is_file():
+        if have_cache:
+            if self.rank != 0:
+                return None
             matrix = matrix_from_squareform(cached)
             log.info(f"read cached matrix in {time.perf_counter() - t0:.3f} s")
         else:
             matrix = matrix_de_novo(self.genomes, METRICS[self.metric], cpus)
-            log.info(f"filled {len(matrix)} x {len(matrix)} matrix on the GPU in {time.perf_counter() - t0:.3f} s (incl. packing)")
+            if matrix is None:                # not rank 0: this rank's shard went into the gather, nothing else to do
+                return None
+            wall = time.perf_counter() - t0
+            st = _matrix.LAST_FILL
+            pairs = st.get("genome_pairs", 0)
+            line = (f"filled {len(matrix)} x {len(matrix)} matrix on {st.get('n_gpus', 1)} GPU(s) in {wall:.3f} s "
+                    f"(pack {st.get('pack_s', 0.0):.3f}, upload {st.get('upload_s', 0.0):.3f}, fill+gather+D2H {st.get('fill_s', 0.0):.3f}): "
+                    f"{pairs / max(st.get('fill_s', 0.0), 1e-9):.3e} genome-pairs/s")
+            if st.get("n_cells"):
+                line += (f"; rank 0: {st['n_alignments']} alignments, {st['n_cells']:.3e} DP cells, "
+                         f"{st['n_distinct_cells'] / max(st['ms_align'], 1e-6) / 1e6:.0f} GCUPS in the alignment kernels")
+            log.info(line)
             matrix_to_squareform(matrix, cached, lower_triangle=True)
         if not matrix.is_distance:
             matrix.invert()
@@ -208,8 +248,11 @@ def phamclust(infile, outdir, is_genome_dir, metric, nr_distance, nr_linkage, cl
     for key, value in settings.items():
         log.info(f"{key:<11}{value}")
     run = _Run(outdir, metric, colors, midpoint)
+    run.rank, run.world = distributed.ensure_process_group()      # (0, 1) unless started by torch.distributed.run
     run.read(infile, is_genome_dir)
     matrix = run.distances(cpus)
+    if matrix is None:                        # ranks other than 0 are done once their shard is gathered
+        return
     multi, single = run.clusters(matrix, (nr_distance, nr_linkage), (clu_distance, clu_linkage))
     run.banner(4, "sub-clusters")
     run.stage = run._dir(run.cache / "03_clusters")
@@ -246,17 +289,32 @@ def main(argv=None):
         kind = "genome directory" if args.genome_dir else "input TSV"
         print(f"{kind} '{args.infile}' does not exist")
         sys.exit(1)
+    rank, _, world = distributed.env_world()
+    if args.gpus > 1 and world == 1:
+        # `--gpus N`: re-run this command line as N ranks, one per GPU, under the launcher -- as a child process,
+        # before this process has made a single GPU call
+        passed = list(sys.argv[1:] if argv is None else argv)
+        sys.exit(distributed.launch_ranks(args.gpus, "phamclust_amd", [str(x) for x in passed]))
     args.outdir.mkdir(parents=True, exist_ok=True)
-    logging.basicConfig(filename=args.outdir / "phamclust.log", filemode="w", format=LOG_STR_FMT, datefmt=LOG_TIME_FMT,
-                        level=logging.DEBUG if args.debug else logging.INFO, force=True)
-    log.addHandler(logging.StreamHandler(sys.stdout))
+    if rank == 0:
+        logging.basicConfig(filename=args.outdir / "phamclust.log", filemode="w", format=LOG_STR_FMT, datefmt=LOG_TIME_FMT,
+                            level=logging.DEBUG if args.debug else logging.INFO, force=True)
+        log.addHandler(logging.StreamHandler(sys.stdout))
+    else:                                     # rank 0 owns the log file and the output tree
+        logging.basicConfig(stream=sys.stderr, format=f"phamclust[rank {rank}]: %(levelname)s: %(message)s", level=logging.WARNING, force=True)
     as_distance = lambda similarity: round(1.0 - similarity, 6)          # noqa: E731
-    phamclust(infile=args.infile, outdir=args.outdir, is_genome_dir=args.genome_dir, metric=args.metric,
-              nr_distance=as_distance(args.nr_thresh), nr_linkage=args.nr_linkage,
-              clu_distance=as_distance(args.clu_thresh), clu_linkage=args.clu_linkage,
-              sub_distance=as_distance(args.sub_thresh), sub_linkage=args.sub_linkage, k_min=max(1, args.k_min),
-              no_sub=args.no_sub, colors=_colors(args.heatmap_colors), midpoint=round(args.heatmap_midpoint, 6),
-              cpus=args.threads, rm_tmp=args.remove_tmp, debug=args.debug)
+    try:
+        phamclust(infile=args.infile, outdir=args.outdir, is_genome_dir=args.genome_dir, metric=args.metric,
+                  nr_distance=as_distance(args.nr_thresh), nr_linkage=args.nr_linkage,
+                  clu_distance=as_distance(args.clu_thresh), clu_linkage=args.clu_linkage,
+                  sub_distance=as_distance(args.sub_thresh), sub_linkage=args.sub_linkage, k_min=max(1, args.k_min),
+                  no_sub=args.no_sub, colors=_colors(args.heatmap_colors), midpoint=round(args.heatmap_midpoint, 6),
+                  cpus=args.threads, rm_tmp=args.remove_tmp, debug=args.debug)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

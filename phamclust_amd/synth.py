@@ -81,3 +81,18 @@ def write_tsv(genomes, filepath):
                 for translation in translations:
                     handle.write(f"{genome.name}\t{pham}\t{translation}\n")
     return filepath
+
+
+def write_tsv_packed(packed, filepath):
+    """The same TSV straight from packed arrays (no Genome objects): genes in packed order, i.e. per genome sorted
+    by pham id -- one of the many line orders that load back to the same genomes."""
+    res = packed.residues.tobytes()
+    seq_off = packed.seq_off.tolist()
+    gene_pham = packed.gene_pham.tolist()
+    phams = [name.encode() for name in packed.pham_names]
+    with open(filepath, "wb") as handle:
+        for g, name in enumerate(packed.names):
+            prefix = name.encode() + b"\t"
+            k0, k1 = int(packed.gene_off[g]), int(packed.gene_off[g + 1])
+            handle.write(b"".join(prefix + phams[gene_pham[k]] + b"\t" + res[seq_off[k]:seq_off[k + 1]] + b"\n" for k in range(k0, k1)))
+    return filepath

@@ -90,3 +90,90 @@ def test_gloo_shard_gather_assemble(native_built, world):
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def _balanced_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from phamclust_amd import distributed as D
+    from phamclust_amd.synth import synth_packed
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      PHAMCLUST_DIST_BACKEND="gloo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        packed = synth_packed(37, 300, seed=9)
+        n = packed.n_genomes
+        costs = _target_cells(packed)          # DP cells behind each target genome, as the device pass counts them
+        t_rank, t_lbase, stride = D.balanced_deal(costs, world)
+        assert (np.bincount(t_rank, minlength=world) > 0).all()
+        shard = torch.zeros(max(stride, 1), dtype=torch.float64)
+        for t in range(1, n):
+            if t_rank[t] == rank:
+                for s_ in range(t):
+                    shard[t_lbase[t] + s_] = O.pair(packed, "peq", s_, t, as_distance=True)
+        gathered = torch.empty(world * max(stride, 1), dtype=torch.float64) if rank == 0 else None
+        dist.gather(shard, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+        flag = D.broadcast_flag(rank == 0 and True, src=0)          # the pipeline's one control-plane broadcast
+        if rank == 0:
+            got = D.assemble_table_host(gathered.numpy().reshape(world, -1), n, t_rank, t_lbase)
+            want = O.fill(packed, "peq", as_distance=True)
+            loads = [int(costs[t_rank == r].sum()) for r in range(world)]
+            q.put((bool(np.array_equal(got, want)), flag, max(loads) / (sum(loads) / world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _target_cells(packed):
+    """sum over s < t of the DP cells of pair (s, t): per shared pham, (summed gene length in s) x (summed gene length in t)."""
+    n = packed.n_genomes
+    length = {}                                             # (genome, pham) -> summed translation length
+    for g in range(n):
+        for k in range(int(packed.gene_off[g]), int(packed.gene_off[g + 1])):
+            key = (g, int(packed.gene_pham[k]))
+            length[key] = length.get(key, 0) + int(packed.seq_off[k + 1] - packed.seq_off[k])
+    by_genome = [{} for _ in range(n)]
+    for (g, pham), ln in length.items():
+        by_genome[g][pham] = ln
+    costs = np.zeros(n, dtype=np.uint64)
+    for t in range(1, n):
+        costs[t] = sum(ln * by_genome[s][pham] for s in range(t) for pham, ln in by_genome[t].items() if pham in by_genome[s])
+    return costs
+
+
+def test_gloo_world2_balanced_deal(native_built):
+    """World-2 gloo run of the COST-BALANCED deal (pc_set_shard_balanced's host mirror, distributed.balanced_deal):
+    each rank fills the targets it was dealt, one gather, table-driven assembly == the unsharded matrix, and the
+    dealt alignment work is level."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_balanced_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    equal, flag, imbalance = q.get(timeout=10)
+    assert equal is True and flag is True and imbalance < 1.05
+
+
+def test_balanced_deal_mirror_properties():
+    from phamclust_amd import distributed as D
+    rng = np.random.default_rng(3)
+    for n, world in ((1, 2), (7, 3), (200, 8), (53, 64)):
+        costs = rng.integers(0, 10**9, n).astype(np.uint64)
+        t_rank, t_lbase, stride = D.balanced_deal(costs, world)
+        fill = [0] * world
+        for t in range(n):
+            assert t_lbase[t] == fill[t_rank[t]]
+            fill[t_rank[t]] += t
+        assert stride == max(fill) and sum(fill) == n * (n - 1) // 2
+    t_rank, _, _ = D.balanced_deal(np.array([5, 5, 5, 5], dtype=np.uint64), 2, pair_floor=0)
+    assert t_rank.tolist() == [0, 1, 0, 1]                  # ties: lower index first, lowest rank first

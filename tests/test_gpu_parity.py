@@ -453,6 +453,74 @@ def test_full_size_peq_properties(gpu_ctx, native_built):
     assert np.array_equal(dist[idx], O.pairs(packed, "peq", lo, hi, as_distance=True))
 
 
+def test_config2_peq_2000_full_fill(gpu_ctx, native_built):
+    """BASELINE configs[2]: synth(2000,5000) -m peq on one GPU (1,999,000 pairs, ~6.5 M alignments, ~3.9e11 DP cells).
+    The whole matrix: determinism, range, peq == round(af * aai, 6) against three independent fills, zero exactly
+    where nothing is shared, a 3-way cost-balanced shard assembling to the same matrix, and 24,000 random pairs
+    (aai and peq, distance and similarity) equal to the oracle."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(2000, 5000)
+    gpu_ctx.upload(packed)
+    n = packed.n_genomes
+    peq, st = gpu_ctx.fill("peq", as_distance=False, want_stats=True)
+    assert peq.shape == (1999000,) and st["n_pairs"] == 1999000
+    assert 6.0e6 < st["n_alignments"] < 7.0e6 and 3.5e11 < st["n_cells"] < 4.3e11        # SURVEY 8(d): 6.52 M, 3.90e11
+    assert np.array_equal(gpu_ctx.fill("peq", as_distance=False), peq)
+    assert peq.min() >= 0.0 and peq.max() <= 1.0
+    af, aai, jc = (gpu_ctx.fill(m, as_distance=False) for m in ("af", "aai", "jc"))
+    py_round = lambda arr: np.array([round(v, 6) for v in arr.tolist()])
+    assert np.array_equal(peq, py_round(af * aai))
+    assert not peq[jc == 0.0].any() and (aai[jc > 0.0] > 0.0).all()
+    dist = gpu_ctx.fill("peq", as_distance=True)
+    assert np.array_equal(dist, py_round(1.0 - af * aai))
+    stream = torch.cuda.current_stream().cuda_stream
+    parts = []
+    for rank in range(3):
+        gpu_ctx.set_shard(rank, 3, balanced=True)
+        buf = torch.empty(gpu_ctx.shard_stride(), dtype=torch.float64, device="cuda:0")
+        gpu_ctx.fill_shard_dev("peq", True, buf.data_ptr(), stream)
+        parts.append(buf)
+    out = torch.empty(packed.n_pairs, dtype=torch.float64, device="cuda:0")
+    gathered = torch.cat(parts)
+    gpu_ctx.assemble_dev(gathered.data_ptr(), 3, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    gpu_ctx.set_shard(0, 1)
+    assert np.array_equal(out.cpu().numpy(), dist)
+    rng = np.random.default_rng(2000)
+    a, b = rng.integers(0, n, 25000), rng.integers(0, n, 25000)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    keep = lo < hi
+    lo, hi = lo[keep][:24000], hi[keep][:24000]
+    assert lo.size == 24000
+    idx = lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)
+    assert np.array_equal(dist[idx], O.pairs(packed, "peq", lo, hi, as_distance=True))
+    assert np.array_equal(peq[idx], O.pairs(packed, "peq", lo, hi, as_distance=False))
+    assert np.array_equal(aai[idx], O.pairs(packed, "aai", lo, hi, as_distance=False))
+
+
+def test_balanced_deal_equals_host_mirror(gpu_ctx, native_built):
+    """The device-side cost-balanced deal (pc_set_shard_balanced) and its host mirror (distributed.balanced_deal, what the
+    CPU tests of the N>1 path use) are the same partition, and pc_shard_table describes the closed-form deal too."""
+    from phamclust_amd import distributed as D
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(173, 900, seed=31)
+    gpu_ctx.upload(packed)
+    for world in (2, 3, 8):
+        gpu_ctx.set_shard(0, world, balanced=True)
+        costs = gpu_ctx.target_costs()
+        t_rank, t_lbase = gpu_ctx.shard_table()
+        m_rank, m_lbase, m_stride = D.balanced_deal(costs, world)
+        assert np.array_equal(t_rank, m_rank) and np.array_equal(t_lbase, m_lbase) and gpu_ctx.shard_stride() == m_stride
+        gpu_ctx.set_shard(1, world, balanced=False)
+        t_rank, t_lbase = gpu_ctx.shard_table()
+        for r in range(world):
+            owned, lbase = D.shard_layout(packed.n_genomes, r, world)
+            assert (t_rank[owned] == r).all() and np.array_equal(t_lbase[owned], lbase[:-1])
+    gpu_ctx.set_shard(0, 1)
+
+
 def test_balanced_deal(gpu_ctx, native_built):
     """pc_set_shard_balanced: every target genome is owned once, the shards assemble to the unsharded matrix for
     a set metric and an alignment metric, and the alignment work per rank is level (genomes of very different size)."""
