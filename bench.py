@@ -12,12 +12,22 @@ packed genomes already resident in HBM.  With N ranks the SAME matrix is filled 
 
 Extra objects on that line:
   roofline      the dominant kernels (the K4 alignment launches of one fill, timed with HIP
-                events on the stream they run on, inside the library): algorithmic bytes =
-                sum(la+lb) residues read + 16 B per alignment (bucket entry in, result out).
-                The kernel is integer-VALU bound, not HBM bound, so the fraction is small by
-                construction; GCUPS (DP cell updates / s) is reported next to it.
+                events on the stream they run on, inside the library).  The recurrence is bound
+                by 32-bit integer VALU issue: every instruction class of the 15-instruction DP
+                cell retires one wave64 instruction per 4 clocks per SIMD (measured:
+                profiles/valu_issue_rate.json), so peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
+                lane-ops/s and achieved = 15 x DP cells computed / kernel time.  `hbm` inside it
+                is the figure the north star asks for: algorithmic bytes = sum(la+lb) residues
+                read + 16 B per alignment (bucket entry in, result out) against 8 TB/s -- small
+                by construction.  `traffic` = HBM bytes of those launches from rocprofv3 PMC
+                passes (profiles/traffic.json), reported only when they were taken on the same
+                kernel sources as the library that is running.
   cpu_baseline  the oracle (C restatement of the reference path, OpenMP over rows) timed on
-                this host on a bounded sample of the same workload (leading matrix rows).
+                this host on a bounded sample of the same workload (leading matrix rows), on
+                every core the process may use, plus a one-thread sample.
+  wall_ms_incl_upload_d2h   SURVEY 8(d)'s wall time of one matrix: upload of the packed genomes
+                + kernels + D2H of the condensed vector (never `value`).
+Exit status 1 (and "valid": false) when the sampled oracle check is not bit-exact.
 """
 
 import argparse
@@ -46,7 +56,7 @@ def parse():
 def cpu_baseline(packed, metric, min_seconds):
     """Oracle (kind 'port') on leading rows until >= min_seconds of work (<= ~2.5x that)."""
     from oracle import oracle as O
-    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    threads = max(1, len(os.sched_getaffinity(0)))          # every core this process may run on
     n = packed.n_genomes
     rows_done, pairs, aln, cells, elapsed = 0, 0, 0, 0, 0.0
     chunk = 1
@@ -69,10 +79,39 @@ def cpu_baseline(packed, metric, min_seconds):
     dt1 = time.perf_counter() - t0
     pairs1 = sum(n - 1 - s for s in range(one_rows))
     single = {"value": pairs1 / dt1, "cores": 1, "gcups": c1 / dt1 / 1e9, "seconds": dt1, "rows": one_rows}
-    return {"value": pairs / elapsed, "unit": "genome-pairs/s", "cores": threads, "kind": "port", "single_thread": single,
-            "sample": f"oracle/pc_oracle.c (OpenMP, {threads} threads) on matrix rows [0,{rows_done}) of the same workload: "
-                      f"{pairs} pairs, {aln} alignments, {cells} DP cells in {elapsed:.2f} s",
-            "gcups": cells / elapsed / 1e9, "seconds": elapsed}
+    out = {"value": pairs / elapsed, "unit": "genome-pairs/s", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
+           "single_thread": single,
+           "sample": f"oracle/pc_oracle.c (OpenMP, {threads} threads) on matrix rows [0,{rows_done}) of the same workload: "
+                     f"{pairs} pairs, {aln} alignments, {cells} DP cells in {elapsed:.2f} s",
+           "gcups": cells / elapsed / 1e9, "seconds": elapsed,
+           "vs_reference_note": "a compiled C port, i.e. a GENEROUS stand-in for the reference's Python + joblib path; the reference "
+                                "itself cannot travel to this box"}
+    try:                                                  # how the port relates to the real reference (build container, one thread)
+        with open(os.path.join(REPO, "profiles", "calibration_reference_vs_oracle.json")) as fh:
+            cal = json.load(fh)
+        ratios = {row["metric"]: round(row["oracle_over_reference_t1"], 1) for row in cal["rows"]}
+        out["calibration_vs_reference"] = {
+            "source": "profiles/calibration_reference_vs_oracle.json (live reference matrix_de_novo -t 1 vs this port -t 1, synth(400,5000), identical values)",
+            "port_over_reference_one_thread": ratios,
+            "aai_peq": "not calibratable: parasail is absent from the reference tree and this image; the reference's README quotes "
+                       "~475-500 peq pairs/s on an Apple M1"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources and headers the library is built from: PMC records are only quoted for the build they
+    were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(REPO, "phamclust_amd", "csrc")
+    for name in ("pc_common.h", "pc_api.hip", "pc_nw.hip", "pc_pairs.hip", "pc_plan.hip"):
+        with open(os.path.join(base, name), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(REPO, "include", "phamclust_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -182,34 +221,43 @@ def main():
         # this rank-set's K4 launches of one fill; multi-GPU: work of all ranks / slowest rank's time
         algo_bytes = n_rbytes + 16 * n_aln
         per_gpu_time = ms_align / 1e3
-        achieved = algo_bytes / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
-        line["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": None,
-            "kernel": "k_nw_systolic<W> (all variant launches of one fill, per GPU)",
-            "algorithmic_bytes_per_fill": algo_bytes, "ms_kernels_per_fill": ms_align,
-            "n_alignments": n_aln, "dp_cells": n_cells,
-            # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
-            "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells,
-            "gcups_per_gpu": n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0,
-            "note": "integer-VALU bound recurrence (no MFMA, little HBM traffic): GCUPS is the meaningful rate; "
-                    "HBM fraction reported because the north star asks for it",
-        }
-        # the bound that actually binds: 32-bit integer VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
-        # (one wave64 VALU instruction occupies its SIMD for 4 clocks; SQ_ACTIVE_INST_VALU confirms it), and
-        # the hand-scheduled DP cell is 15 VALU instructions.
+        hbm_achieved = algo_bytes / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
+        gcups = n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
+        # The bound that binds: 32-bit integer VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: a wave64 VALU
+        # instruction of every class the DP cell uses (v_cmp -> SGPR, v_cndmask, v_max_i32, v_max3, SDWA, v_addc) holds its
+        # SIMD for 4 clocks at any occupancy (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json; only plain
+        # add/sub/and/or/xor/mov, f32 add/fma and the 16-bit max/add go at 2), and the hand-scheduled cell is 15 of them.
+        instr_per_cell = 15
         lane_ops_peak = 256 * 4 * 16 * 2.4e9
-        gc = line["roofline"]["gcups_per_gpu"]
-        line["roofline"]["valu"] = {"bound": "int32 VALU issue", "instr_per_cell": 15, "peak_gcups": lane_ops_peak / 15 / 1e9,
-                                    "achieved_gcups": gc, "frac": gc / (lane_ops_peak / 15 / 1e9)}
+        lane_ops = instr_per_cell * gcups * 1e9
+        line["roofline"] = {
+            "bound": "valu", "achieved": lane_ops / 1e12, "peak": lane_ops_peak / 1e12, "unit": "Tlane-op/s (int32 VALU)",
+            "frac": lane_ops / lane_ops_peak, "traffic": None,
+            "kernel": "k_nw_systolic<W,RULE> (all variant launches of one fill, per GPU)",
+            "instr_per_cell": instr_per_cell, "peak_gcups": lane_ops_peak / instr_per_cell / 1e9, "achieved_gcups": gcups,
+            "issue_rate_source": "profiles/valu_issue_rate.json (4.0-4.15 clk per wave64 instruction per SIMD for every class in the cell)",
+            "ms_kernels_per_fill": ms_align, "n_alignments": n_aln, "dp_cells": n_cells,
+            # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
+            "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells, "gcups_per_gpu": gcups,
+            "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": 8000.0, "unit": "GB/s", "frac": hbm_achieved / 8000.0,
+                    "algorithmic_bytes_per_fill": algo_bytes,
+                    "note": "sum(la+lb) residues + 16 B per alignment over the kernels' time: far below HBM speed by construction "
+                            "(the recurrence is integer-VALU bound, no MFMA: there is no dense contraction)"},
+        }
         if align_span:
             line["roofline"]["ms_kernels_min_max_over_ranks"] = align_span
-        try:                                              # PMC traffic measured offline for this exact workload, if any
+        src_hash = kernel_source_hash()
+        line["kernel_source_hash"] = src_hash
+        try:                                              # PMC traffic measured offline for this exact workload AND these sources
             with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
                 for e in json.load(fh)["entries"]:
                     if e["workload"] == f"synth({a.genomes},{a.phams}) -m {a.metric}" and e["n_gpus"] == world:
-                        line["roofline"]["traffic"] = e["traffic_bytes_per_fill"]
-                        line["roofline"]["traffic_source"] = e["source"]
+                        if e.get("kernel_source_hash") == src_hash:
+                            line["roofline"]["traffic"] = e["traffic_bytes_per_fill"]
+                            line["roofline"]["traffic_source"] = e["source"]
+                        else:
+                            line["roofline"]["traffic_stale"] = {"bytes_per_fill": e["traffic_bytes_per_fill"], "source": e["source"],
+                                                                 "taken_on_kernel_source_hash": e.get("kernel_source_hash")}
         except (OSError, KeyError, ValueError):
             pass
     else:
@@ -238,11 +286,28 @@ def main():
         want = O.pairs(packed, a.metric, lo, hi, as_distance=True)
         line["verified"] = {"pairs": int(lo.size), "how": "random pairs of the full matrix vs oracle/pc_oracle.c",
                             "max_abs_diff": float(np.max(np.abs(got - want))), "bit_exact": bool(np.array_equal(got, want))}
+    if world == 1:
+        # SURVEY 8(d)'s wall time of one matrix: upload + kernels + D2H of the condensed vector (host clock, second of two)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.upload(packed)
+            t1 = time.perf_counter()
+            host = ctx.fill(a.metric, True, borrow=True)
+            t2 = time.perf_counter()
+        line["wall_ms_incl_upload_d2h"] = (t2 - t0) * 1e3
+        line["wall_breakdown_ms"] = {"upload": (t1 - t0) * 1e3, "kernels_plus_d2h_to_pinned_host": (t2 - t1) * 1e3}
+        line["pairs_per_s_incl_upload_d2h"] = n_pairs / (t2 - t0) if n_pairs else 0.0
+        assert host.shape[0] == n_pairs
     if world == 1 and a.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(packed, a.metric, a.cpu_seconds)
+    valid = bool(line.get("verified", {}).get("bit_exact", True))
+    line["valid"] = valid
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not valid:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

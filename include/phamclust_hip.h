@@ -125,6 +125,11 @@ int pc_target_costs(const pc_ctx* ctx, uint64_t* cost);
  */
 int pc_fill(pc_ctx* ctx, int metric, int as_distance, double* out_condensed, pc_stats* stats);
 
+/* Same values, delivered in page-locked host memory owned by the context (grow-only, pinned once): *out_host points to
+ * f64[N(N-1)/2] and stays valid until the next fill or upload on this context, or its destruction.  This is the call
+ * matrix_de_novo uses: the result is expanded into the SymMatrix straight away, so nothing outlives the loan. */
+int pc_fill_borrow(pc_ctx* ctx, int metric, int as_distance, const double** out_host, pc_stats* stats);
+
 /* Same, result left in HBM: out_dev is a device pointer to f64[N(N-1)/2]; `stream` is a
  * hipStream_t; NULL is the legacy default stream, as everywhere in HIP (PyTorch's default stream has
  * handle 0: work the caller queued there is ordered with these launches).  Asynchronous w.r.t. the host except for

@@ -92,6 +92,7 @@ struct pc_ctx {
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
     DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
+    double* h_out = nullptr; size_t h_out_cap = 0;   // pinned result buffer lent out by pc_fill_borrow (grow-only)
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     static constexpr int kAux = 7;          // + the caller's stream = 8 concurrent alignment launches
@@ -175,6 +176,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     for (int i = 0; i < pc_ctx::kAux; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
     for (int i = 0; i <= pc_ctx::kAux; ++i) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
     if (c->h_plan) (void)hipHostFree(c->h_plan);
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -717,6 +719,33 @@ extern "C" int pc_fill(pc_ctx* c, int metric, int as_distance, double* out_conde
     if (np) PC_HIP(hipMemcpyAsync(out_condensed, c->b_out.p, np * 8, hipMemcpyDeviceToHost, c->stream));
     PC_HIP(hipStreamSynchronize(c->stream));
     c->busy = false;
+    return PC_OK;
+}
+
+// Whole matrix into page-locked host memory that the CONTEXT owns: the D2H copy of an N = 20,000 matrix (1.6 GB) runs at
+// PCIe speed (~30 ms) instead of through pageable staging (~165 ms), and the 1.6 GB are pinned once, not per call.
+// *out_host stays valid until the next fill / upload on this context or its destruction.
+extern "C" int pc_fill_borrow(pc_ctx* c, int metric, int as_distance, const double** out_host, pc_stats* stats) {
+    if (!c || !c->uploaded) { pc_set_error("pc_fill_borrow: upload first"); return PC_ERR_STATE; }
+    if (!out_host) { pc_set_error("pc_fill_borrow: out_host is NULL"); return PC_ERR_ARG; }
+    *out_host = nullptr;
+    PC_ON_DEVICE(c);
+    int rc = PC_OK;
+    const int64_t np = (int64_t)c->dev.N * (c->dev.N - 1) / 2;
+    const size_t bytes = (size_t)std::max<int64_t>(np, 1) * 8;
+    if ((rc = c->b_out.ensure(bytes))) return rc;
+    if (bytes > c->h_out_cap) {
+        if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; }
+        const size_t want = bytes + bytes / 8;
+        hipError_t e = hipHostMalloc((void**)&c->h_out, want, hipHostMallocDefault);
+        if (e != hipSuccess) { pc_set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); c->h_out = nullptr; return PC_ERR_HIP; }
+        c->h_out_cap = want;
+    }
+    if ((rc = pc_fill_dev(c, metric, as_distance, c->b_out.p, c->stream, stats))) return rc;
+    if (np) PC_HIP(hipMemcpyAsync(c->h_out, c->b_out.p, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
+    PC_HIP(hipStreamSynchronize(c->stream));
+    c->busy = false;
+    *out_host = c->h_out;
     return PC_OK;
 }
 

@@ -86,10 +86,10 @@ __device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh,
 }
 
 // ---------------------------------------------------------------------------------
-// K1+K3: gcs / jc.  shared = popcount(B[s] & B[t]); fp64 epilogue.  One 512-thread workgroup
-// per 64x64 tile of pairs, a 2x4 register tile of pairs per thread: per bitmap word a thread
-// reads 2 source-row words and 4 target-row words from LDS (broadcast / conflict-free with
-// the odd row stride) and does 8 AND+popcount pairs.  Lanes 0..15 of a 16-lane group hold
+// K1+K3: gcs / jc.  shared = popcount(B[s] & B[t]); fp64 epilogue.  One 256-thread workgroup
+// per 64x64 tile of pairs, a 4x4 register tile of pairs per thread: per bitmap word a thread
+// reads 4 source-row words and 4 target-row words from LDS (broadcast / conflict-free with
+// the odd row stride) and does 16 AND+popcount pairs.  Lanes 0..15 of a 16-lane group hold
 // consecutive t, so each store instruction writes 128-byte runs of the condensed output.
 // The epilogue value depends only on the two small integers (shared, nph_s + nph_t), so it is
 // looked up in a table built once per fill by k_set_lut (exactly the same fp64 code path:
@@ -119,80 +119,71 @@ __global__ void k_set_lut(double* __restrict__ lut, int sh_dim, int tot_dim, int
 }
 
 template <int METRIC>
-__global__ __launch_bounds__(512) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
+__global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
                                                    const double* __restrict__ lut, int sh_dim) {
     __shared__ uint64_t rs[PT][PWCH + 1];
     __shared__ uint64_t rt[PT][PWCH + 1];
     const int s0 = blockIdx.x * PT, k0 = blockIdx.y * PT;
     const int klast = min(k0 + PT, sh.nown) - 1;
     if (s0 >= sh.owned[klast]) return;                       // tile entirely on/below the diagonal
-    // fast index (16 lanes) along the output's contiguous direction: t (condensed) or s (shard-local)
-    const int fx = threadIdx.x & 15, fy = threadIdx.x >> 4;  // fy: 0..31
-    // the fast direction holds 4 values per thread (+16j), the slow one 2 (+32i)
-    int acc[2][4];
+    // 256 threads = 16 (fx) x 16 (fy), a 4x4 register tile of pairs each: per bitmap word a thread reads 4 + 4 row words
+    // from LDS for 16 AND+popcount pairs (0.5 LDS reads per pair-word: the loop is VALU-bound -- v_and at 2 clocks and
+    // v_bcnt at 4 per wave64, profiles/valu_issue_rate.json -- not LDS-bound).  fx runs along the output's contiguous
+    // direction: t (condensed) or s (shard-local), so each store instruction writes 128-byte runs.
+    const int fx = threadIdx.x & 15, fy = threadIdx.x >> 4;
+    int acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0;
-    // staging: thread (r0 = tid>>5, w = tid&31) moves word w of rows r0, r0+16, r0+32, r0+48 of both tiles.
-    // The next chunk's words are fetched into registers while the current chunk is being counted.
+    // staging: thread (r0 = tid>>5, w = tid&31) moves word w of rows r0 + 8p (p < 8) of both tiles; the next chunk's
+    // words are fetched into registers while the current chunk is being counted
     const int r0 = threadIdx.x >> 5, wl = threadIdx.x & 31;
-    const uint64_t* ps[4]; const uint64_t* pt[4];
+    const uint64_t* ps[8]; const uint64_t* pt[8];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int s = s0 + r0 + 16 * p, k = k0 + r0 + 16 * p;
+    for (int p = 0; p < 8; ++p) {
+        const int s = s0 + r0 + 8 * p, k = k0 + r0 + 8 * p;
         ps[p] = s < d.N ? d.bitmap + (int64_t)s * d.Wstride : nullptr;
         pt[p] = k < sh.nown ? d.bitmap + (int64_t)sh.owned[k] * d.Wstride : nullptr;
     }
-    uint64_t vs[4], vt[4];
+    uint64_t vs[8], vt[8];
     auto fetch = [&](int w0) {
         const int w = w0 + wl;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < 8; ++p) {
             vs[p] = (ps[p] && w < d.Wb) ? ps[p][w] : 0ULL;
             vt[p] = (pt[p] && w < d.Wb) ? pt[p][w] : 0ULL;
         }
     };
+    // the rows a thread reads: the slow index takes the tile's s rows under condensed output, its t rows otherwise
+    uint64_t (*ra)[PWCH + 1] = condensed ? rs : rt;
+    uint64_t (*rb)[PWCH + 1] = condensed ? rt : rs;
     fetch(0);
     for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
         const int wn = min(PWCH, d.Wb - w0);
         if (w0) __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { rs[r0 + 16 * p][wl] = vs[p]; rt[r0 + 16 * p][wl] = vt[p]; }
+        for (int p = 0; p < 8; ++p) { rs[r0 + 8 * p][wl] = vs[p]; rt[r0 + 8 * p][wl] = vt[p]; }
         __syncthreads();
         if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
-        if (condensed) {
-            for (int w = 0; w < wn; ++w) {
-                uint64_t a[2], b[4];
+        for (int w = 0; w < wn; ++w) {
+            uint64_t a[4], b[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = rs[fy + 32 * i][w];
+            for (int i = 0; i < 4; ++i) a[i] = ra[fy + 16 * i][w];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = rt[fx + 16 * j][w];
+            for (int j = 0; j < 4; ++j) b[j] = rb[fx + 16 * j][w];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
-            }
-        } else {
-            for (int w = 0; w < wn; ++w) {
-                uint64_t a[2], b[4];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = rt[fy + 32 * i][w];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = rs[fx + 16 * j][w];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ls = condensed ? fy + 32 * i : fx + 16 * j;
-            const int lt = condensed ? fx + 16 * j : fy + 32 * i;
+            const int ls = condensed ? fy + 16 * i : fx + 16 * j;
+            const int lt = condensed ? fx + 16 * j : fy + 16 * i;
             const int s = s0 + ls, k = k0 + lt;
             if (s >= d.N || k >= sh.nown) continue;
             const int t = sh.owned[k];
@@ -213,8 +204,8 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
         if (metric == PC_GCS) hipLaunchKernelGGL(k_set_lut<PC_GCS>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
         else hipLaunchKernelGGL(k_set_lut<PC_JC>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
     }
-    if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(512), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
-    else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(512), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+    if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+    else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_set_popc launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;

@@ -42,7 +42,7 @@ class PcStats(ctypes.Structure):
 
 
 EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
-           "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
+           "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs"]
 
 _lib = None
@@ -81,6 +81,7 @@ def load():
     L.pc_shard_stride.argtypes = [vp]
     L.pc_shard_stride.restype = ctypes.c_int64
     L.pc_fill.argtypes = [vp, ctypes.c_int, ctypes.c_int, _f64p, ctypes.POINTER(PcStats)]
+    L.pc_fill_borrow.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_f64p), ctypes.POINTER(PcStats)]
     L.pc_fill_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
     L.pc_fill_shard_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
     L.pc_assemble_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
@@ -180,10 +181,18 @@ class Context:
         return int(self._lib.pc_shard_stride(self._h))
 
     # -- fills -------------------------------------------------------------------
-    def fill(self, metric, as_distance=True, want_stats=False):
-        """Whole matrix -> host condensed f64 vector (scipy order)."""
-        out = np.empty(max(self.n_pairs, 0), dtype=np.float64)
+    def fill(self, metric, as_distance=True, want_stats=False, borrow=False):
+        """Whole matrix -> host condensed f64 vector (scipy order).  ``borrow=True`` returns a READ-ONLY view of page-locked
+        memory the context owns (no pageable staging: the D2H copy runs at PCIe speed); the view is only good until the
+        next fill or upload on this context -- copy it, or consume it at once as matrix_de_novo does."""
         stats = PcStats()
+        if borrow:
+            ptr = _f64p()
+            self._check(self._lib.pc_fill_borrow(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.byref(ptr), ctypes.byref(stats)))
+            out = np.ctypeslib.as_array(ptr, shape=(max(self.n_pairs, 1),))[:self.n_pairs]
+            out.flags.writeable = False
+            return (out, stats.as_dict()) if want_stats else out
+        out = np.empty(max(self.n_pairs, 0), dtype=np.float64)
         buf = out if out.size else np.zeros(1)
         self._check(self._lib.pc_fill(self._h, METRIC_IDS[metric], int(bool(as_distance)), _ptr(buf, _f64p),
                                       ctypes.byref(stats)))

@@ -364,7 +364,7 @@ def matrix_de_novo(genomes, func, cpus, as_distance=True):
         if world > 1:
             condensed, stats = distributed.fill_condensed(ctx, metric, as_distance)
         else:
-            condensed, stats = ctx.fill(metric, as_distance=as_distance, want_stats=True)
+            condensed, stats = ctx.fill(metric, as_distance=as_distance, want_stats=True, borrow=True)
         t3 = time.perf_counter()
         LAST_FILL.clear()
         LAST_FILL.update(stats, metric=metric, n_genomes=len(genomes), genome_pairs=packed.n_pairs, n_gpus=world, rank=rank,
