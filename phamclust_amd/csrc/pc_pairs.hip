@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
         for (int p = 0; p < 8; ++p) { rs[r0 + 8 * p][wl] = vs[p]; rt[r0 + 8 * p][wl] = vt[p]; }
         __syncthreads();
         if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
+#pragma unroll 2
         for (int w = 0; w < wn; ++w) {
             uint64_t a[4], b[4];
 #pragma unroll
@@ -175,7 +176,12 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += __popcll(a[i] & b[j]);
+                for (int j = 0; j < 4; ++j) {
+                    // two v_bcnt_u32_b32, each adding into the running count (left to itself the compiler counts into a
+                    // temporary and spends a third instruction on the add)
+                    const uint64_t x = a[i] & b[j];
+                    asm("v_bcnt_u32_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %2, %0" : "+v"(acc[i][j]) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)));
+                }
         }
     }
 #pragma unroll

@@ -33,16 +33,16 @@
 enum {
     OP_FMA_F32, OP_PK_FMA_F32, OP_MAX_I32, OP_MAX3_I32, OP_ADD_U32, OP_AND_B32, OP_BCNT, OP_CNDMASK_VCC, OP_CNDMASK_SGPR,
     OP_CMP_VCC, OP_CMP_SGPR, OP_CMP_SDWA_SGPR, OP_ADD_SDWA, OP_ADDC, OP_CNDMASK_DPP_WAVE, OP_MOV_DPP_WAVE, OP_MOV_DPP_ROW,
-    OP_PK_MAX_I16, OP_ADD3_U32, OP_PERM, OP_CNDMASK_VCC_HOISTED, OP_CNDMASK_VCC_E64, OP_MIN_U32, OP_SUB_U32, OP_OR_B32, OP_LSHL_ADD, OP_XOR_B32, OP_MOV_B32, OP_LSHLREV, OP_ASHRREV, OP_MAX_F32, OP_ADD_F32, OP_MUL_U24, OP_MAX_I16, OP_ADD_U16, OP_CELL, OP_STEP_VCC, OP_STEP_NOVCC, OP_COUNT
+    OP_PK_MAX_I16, OP_ADD3_U32, OP_PERM, OP_CNDMASK_VCC_HOISTED, OP_CNDMASK_VCC_E64, OP_MIN_U32, OP_SUB_U32, OP_OR_B32, OP_LSHL_ADD, OP_XOR_B32, OP_MOV_B32, OP_LSHLREV, OP_ASHRREV, OP_MAX_F32, OP_ADD_F32, OP_MUL_U24, OP_MAX_I16, OP_ADD_U16, OP_POPC_MIX, OP_AND_MAX_MIX, OP_CELL, OP_STEP_VCC, OP_STEP_NOVCC, OP_COUNT
 };
 static const char* kOpName[OP_COUNT] = {
     "v_fma_f32", "v_pk_fma_f32", "v_max_i32", "v_max3_i32", "v_add_u32", "v_and_b32", "v_bcnt_u32_b32", "v_cndmask_b32 (vcc)",
     "v_cndmask_b32 (sgpr pair)", "v_cmp_gt_i32 -> vcc", "v_cmp_gt_i32 -> sgpr pair", "v_cmp_eq_u32_sdwa -> sgpr pair",
     "v_add_u32_sdwa", "v_addc_co_u32 (sgpr carry)", "v_cndmask_b32_dpp wave_shr:1", "v_mov_b32_dpp wave_shr:1",
-    "v_mov_b32_dpp row_shr:1", "v_pk_max_i16", "v_add3_u32", "v_perm_b32", "v_cndmask_b32 (vcc set outside the loop)", "v_cndmask_b32_e64 (vcc as sgpr operand)", "v_min_u32", "v_sub_u32", "v_or_b32", "v_lshl_add_u32", "v_xor_b32", "v_mov_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_max_f32", "v_add_f32", "v_mul_u32_u24", "v_max_i16", "v_add_u16",
+    "v_mov_b32_dpp row_shr:1", "v_pk_max_i16", "v_add3_u32", "v_perm_b32", "v_cndmask_b32 (vcc set outside the loop)", "v_cndmask_b32_e64 (vcc as sgpr operand)", "v_min_u32", "v_sub_u32", "v_or_b32", "v_lshl_add_u32", "v_xor_b32", "v_mov_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_max_f32", "v_add_f32", "v_mul_u32_u24", "v_max_i16", "v_add_u16", "popcount tile mix: 32 v_and then 32 v_bcnt (16 chains of 2)", "alternating v_and / v_max_i32",
     "DP cell (15 instr, pc_nw.hip schedule)", "row step: prologue (s_mov vcc + 10 VALU) + 8 cells", "row step: prologue with vcc set outside + 8 cells"};
 // instructions per loop iteration
-static int op_instrs(int op) { return op == OP_CELL ? 15 * 8 : op == OP_STEP_VCC || op == OP_STEP_NOVCC ? 15 * 8 + 11 : 128; }
+static int op_instrs(int op) { return op == OP_CELL ? 15 * 8 : op == OP_STEP_VCC || op == OP_STEP_NOVCC ? 15 * 8 + 11 : op == OP_POPC_MIX ? 128 : 128; }
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k_rate(unsigned long long* __restrict__ out, int iters, int seed) {
@@ -175,6 +175,20 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* __restrict__ 
         } else if constexpr (OP == OP_MOV_B32) {
 #define F(i) "v_mov_b32 %" #i ", %16\n\t"
             BODY();
+#undef F
+        } else if constexpr (OP == OP_POPC_MIX) {
+            // what k_set_popc's inner loop issues per bitmap word: 32 independent v_and, then 16 counters each fed by two
+            // back-to-back v_bcnt (the second reads the first's result); twice per iteration = 128 instructions
+#define ANDS(o) "v_and_b32 %" #o ", %16, %17\n\t"
+#define CNT(o) "v_bcnt_u32_b32 %" #o ", %16, %" #o "\n\tv_bcnt_u32_b32 %" #o ", %17, %" #o "\n\t"
+#define HALF REP16_1(ANDS) REP16_1(ANDS) REP16_1(CNT)
+            asm volatile(HALF HALF : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) : "v"(a), "v"(b));
+#undef HALF
+#undef CNT
+#undef ANDS
+        } else if constexpr (OP == OP_AND_MAX_MIX) {
+#define F(i) "v_and_b32 %" #i ", %16, %17\n\tv_max_i32 %" #i ", %16, %17\n\t"
+            asm volatile(REP16_1(F) REP16_1(F) REP16_1(F) REP16_1(F) : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]), "=v"(r[11]), "=v"(r[12]), "=v"(r[13]), "=v"(r[14]), "=v"(r[15]) : "v"(a), "v"(b));
 #undef F
         } else if constexpr (OP == OP_CNDMASK_SGPR) {
 #define F(i) "v_cndmask_b32 %" #i ", %16, %17, %18\n\t"

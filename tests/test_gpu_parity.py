@@ -175,6 +175,38 @@ def test_tie_rule_table(gpu_ctx, native_built, rule):
         gpu_ctx.set_tie_rule(0)
 
 
+def test_int16_saturation_threshold(gpu_ctx, native_built):
+    """The reference aligns with parasail's 16-bit kernel (`nw_trace_diag_16`, metrics.py:174) and never looks at its
+    saturation flag: once a DP cell passes +32,767 (BLOSUM62's best per-residue score is W/W = 11, so from 2,979
+    identical tryptophans; about 6,000 residues of ordinary protein identical to itself) parasail's table, and with it
+    the reference's identity and length, is garbage.  This build keeps scores in 32 bits on purpose: below
+    the threshold the two cannot differ (every int16 operation is exact there), above it this path stays exact.  Checked
+    here on both sides of the line against the 32-bit oracle and against closed forms."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    lens = (2970, 2978, 2979, 3300)                         # 11 * 2978 = 32,758 < 32,767 < 32,769 = 11 * 2979
+    g, h = Genome("cols"), Genome("rows")
+    for i, n in enumerate(lens):
+        g.add(f"c{i}", "W" * n)
+        h.add(f"r{i}a", "W" * n)                             # identical: score 11 n, identity n / n
+        h.add(f"r{i}b", "W" * (n - 9) + "A" * 9)             # 9 substitutions at the end: no gap can beat them (W/A = -3 > -11)
+        h.add(f"r{i}c", "W" * (n - 40))                      # a 40-residue deletion: one gap run
+    pk = pack_genomes([g, h])
+    ncol = len(lens)
+    a = np.arange(ncol, ncol + 3 * ncol, dtype=np.int32)
+    b = np.repeat(np.arange(ncol, dtype=np.int32), 3)
+    gpu_ctx.upload(pk)
+    ident, diag = gpu_ctx.align_pairs(a, b)
+    score, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+    assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
+    for k, n in enumerate(lens):
+        assert score[3 * k] == 11 * n and (score[3 * k] > 32767) == (n >= 2979)
+        assert ident[3 * k] == n and diag[3 * k] == n                                   # 100 % identity, no gaps
+        assert ident[3 * k + 1] == n - 9 and diag[3 * k + 1] == n                       # (n - 9) / n
+        assert ident[3 * k + 2] == n - 40 and diag[3 * k + 2] == n - 40                 # (n - 40) / n, aln_len == n
+
+
 def test_round6_matches_python(gpu_ctx):
     rng = np.random.default_rng(9)
     xs = np.concatenate([

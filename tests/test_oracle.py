@@ -113,6 +113,58 @@ def test_tie_sensitivity_report_is_committed_and_consistent():
     assert 0.0 < worst["alignments_changed_frac"] < 0.05 and worst["max_abs_d_peq"] < 1e-3
 
 
+def _rules_matching(O, vectors):
+    """Tie rules (0..15) under which the oracle reproduces every (n_ident, aln_len) of the given parasail vectors."""
+    ok = []
+    try:
+        for rule in range(16):
+            O.set_tie_rule(rule)
+            good = True
+            for v in vectors:
+                _, ident, diag = O.nw_stats(v["a"], v["b"])
+                if ident != v["n_ident"] or len(v["a"]) + len(v["b"]) - diag != v["aln_len"]:
+                    good = False
+                    break
+            if good:
+                ok.append(rule)
+    finally:
+        O.set_tie_rule(0)
+    return ok
+
+
+def test_parasail_vectors_select_the_default_rule(O):
+    """Runs only where someone has generated tests/golden/parasail_vectors.json with real parasail
+    (tests/golden/make_parasail_vectors.py; impossible in this image).  Vectors whose score leaves the int16 range
+    are excluded: the reference accepts parasail's saturated garbage there (metrics.py:174), this build computes in
+    32 bits (tests/test_gpu_parity.py::test_int16_saturation_threshold)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(golden_file("gcs")), "parasail_vectors.json")
+    if not os.path.exists(path):
+        pytest.skip("no parasail vectors committed (parasail is not installable here): aligner parity stays UNPINNED")
+    vectors = [v for v in json.load(open(path))["vectors"] if not v.get("saturated") and abs(v["score"]) < 32000]
+    assert len(vectors) >= 100
+    for v in vectors[:50]:
+        assert O.nw_stats(v["a"], v["b"])[0] == v["score"]            # the score does not depend on any tie rule
+    matching = _rules_matching(O, vectors)
+    assert matching, "no tie rule reproduces parasail: a rule beyond the three switches is wrong"
+    assert 0 in matching, f"parasail follows rule(s) {matching}, not the default 0: set PC_TIE_RULE / PC_TIE_RULE_DEFAULT accordingly"
+
+
+def test_parasail_live_cross_check(O):
+    """Opportunistic: with parasail importable, compare directly."""
+    parasail = pytest.importorskip("parasail")
+    rng = random.Random(7)
+    vectors = []
+    for it in range(300):
+        alpha = "AGS" if it % 2 else "ACDEFGHIKLMNPQRSTVWY"
+        a = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 80)))
+        b = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 80)))
+        tb = parasail.nw_trace_diag_16(a, b, 11, 1, parasail.blosum62).get_traceback(mch="|", sim="+", neg=" ")
+        vectors.append({"a": a, "b": b, "aln_len": len(tb.query), "n_ident": tb.comp.count("|")})
+    assert 0 in _rules_matching(O, vectors)
+
+
 def test_aligner_known_answers(O):
     """Math-pinned cases: any correct affine NW (11/1, BLOSUM62) must return these."""
     s = "MKTAYIAKQRQISFVKSHFSRQLEERLGLIEVQ"
