@@ -53,10 +53,32 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_quota():
+    """CPUs this process's cgroup may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: a GPU box
+    with 256 hardware threads may grant its one-GPU tenant 16 of them, and 256 OpenMP threads on 16 CPUs run slower
+    than 16."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            quota = int(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = int(fh.read())
+        return None if quota <= 0 else max(1, quota // period)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(packed, metric, min_seconds):
     """Oracle (kind 'port') on leading rows until >= min_seconds of work (<= ~2.5x that)."""
     from oracle import oracle as O
-    threads = max(1, len(os.sched_getaffinity(0)))          # every core this process may run on
+    affinity = len(os.sched_getaffinity(0))
+    quota = cpu_quota()
+    threads = max(1, min(affinity, quota) if quota else affinity)          # every core this process may actually use
     n = packed.n_genomes
     rows_done, pairs, aln, cells, elapsed = 0, 0, 0, 0, 0.0
     chunk = 1
@@ -79,7 +101,8 @@ def cpu_baseline(packed, metric, min_seconds):
     dt1 = time.perf_counter() - t0
     pairs1 = sum(n - 1 - s for s in range(one_rows))
     single = {"value": pairs1 / dt1, "cores": 1, "gcups": c1 / dt1 / 1e9, "seconds": dt1, "rows": one_rows}
-    out = {"value": pairs / elapsed, "unit": "genome-pairs/s", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
+    out = {"value": pairs / elapsed, "unit": "genome-pairs/s", "cores": threads, "host_cpu_count": os.cpu_count(), "affinity_cpus": affinity,
+           "cgroup_cpu_quota": quota, "kind": "port",
            "single_thread": single,
            "sample": f"oracle/pc_oracle.c (OpenMP, {threads} threads) on matrix rows [0,{rows_done}) of the same workload: "
                      f"{pairs} pairs, {aln} alignments, {cells} DP cells in {elapsed:.2f} s",

@@ -71,6 +71,41 @@ __device__ __forceinline__ int64_t pc_out_index(const PcDev& d, const PcShard& s
     return sh.lbase[k] + s;
 }
 
+// XCD-aware tile order for the pair kernels (1-D grids).  The dispatcher hands workgroups to the 8 XCDs round-robin by
+// flat id, and every XCD has its own 4 MiB L2.  With a plain 2-D grid each XCD sees tiles from everywhere and streams
+// the whole bitmap (plus rank and entry tables) through its L2 again and again: at N = 20,000 the popcount kernel
+// fetched 2.4 GB for a 12.6 MB bitmap, the walker 11 GB (profiles/r02_c_counters.json).  Here tiles are grouped into
+// super-tiles of up to 8 x 8 tiles and consecutive workgroups of one XCD walk one super-tile, so the ~100 workgroups
+// resident on an XCD share the rows of one or two super-tiles (0.29 GB and 1.3 GB after the change).  Affinity only:
+// nothing depends on where a workgroup really runs.
+// Super-tile edge: 8 tiles, halved while that would leave an XCD with fewer than 16 super-tiles (small matrices must
+// still spread over all 8 XCDs; at edge 1 the deal is tile by tile).
+__host__ __device__ __forceinline__ unsigned pc_super_edge(unsigned ntx, unsigned nty) {
+    unsigned e = 8;
+    while (e > 1 && ((ntx + e - 1) / e) * ((nty + e - 1) / e) < 128u) e >>= 1;
+    return e;
+}
+// XCD x takes, in super-tile row sy, the columns sx = 8c + ((x - sy) mod 8): every XCD gets every eighth super-tile of
+// each row AND of each column, so the triangular (or, for a shard, trapezoid) region of live tiles is dealt evenly --
+// dealing whole columns to XCDs left them 40 % apart on the triangle.
+__device__ __forceinline__ bool pc_tile_of_block(int ntx, int nty, int& tx, int& ty) {
+    const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty);
+    const unsigned n = blockIdx.x;
+    const unsigned xcd = n & 7u, k = n >> 3;
+    const unsigned stx = ((unsigned)ntx + e - 1) / e, stx8 = (stx + 7u) / 8u;
+    const unsigned m = k / (e * e), within = k % (e * e);
+    const unsigned sy = m / stx8, c = m % stx8;
+    const unsigned sx = c * 8u + ((xcd + 8u - (sy & 7u)) & 7u);
+    tx = (int)(sx * e + within % e);
+    ty = (int)(sy * e + within / e);
+    return tx < ntx && ty < nty;
+}
+static unsigned pc_tile_grid(int ntx, int nty) {
+    const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty);
+    const unsigned stx = ((unsigned)ntx + e - 1) / e, sty = ((unsigned)nty + e - 1) / e;
+    return sty * ((stx + 7u) / 8u) * 8u * e * e;
+}
+
 // Stage one chunk of bitmap words of the tile's 32 source rows and 32 target rows.
 __device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh, int s0, int k0, int w0, int wn,
                                               uint64_t (*rs)[WCH + 1], uint64_t (*rt)[WCH + 1]) {
@@ -123,7 +158,9 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
                                                    const double* __restrict__ lut, int sh_dim) {
     __shared__ uint64_t rs[PT][PWCH + 1];
     __shared__ uint64_t rt[PT][PWCH + 1];
-    const int s0 = blockIdx.x * PT, k0 = blockIdx.y * PT;
+    int tile_x, tile_y;
+    if (!pc_tile_of_block((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT, tile_x, tile_y)) return;
+    const int s0 = tile_x * PT, k0 = tile_y * PT;
     const int klast = min(k0 + PT, sh.nown) - 1;
     if (s0 >= sh.owned[klast]) return;                       // tile entirely on/below the diagonal
     // 256 threads = 16 (fx) x 16 (fy), a 4x4 register tile of pairs each: per bitmap word a thread reads 4 + 4 row words
@@ -204,7 +241,7 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
 int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed,
                        double* lut, int sh_dim, int tot_dim, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
-    dim3 grid((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT);
+    dim3 grid(pc_tile_grid((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT));
     if (lut) {
         const int n = sh_dim * tot_dim;
         if (metric == PC_GCS) hipLaunchKernelGGL(k_set_lut<PC_GCS>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
@@ -276,7 +313,9 @@ __global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a)
     __shared__ uint64_t rs[TS][WCH + 1];
     __shared__ uint64_t rt[TS][WCH + 1];
     __shared__ unsigned long long red[3];
-    const int s0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
+    int tile_x, tile_y;
+    if (!pc_tile_of_block((d.N + TS - 1) / TS, (sh.nown + TS - 1) / TS, tile_x, tile_y)) return;
+    const int s0 = tile_x * TS, k0 = tile_y * TS;
     const int klast = min(k0 + TS, sh.nown) - 1;
     if (s0 >= sh.owned[klast]) return;
     const int f = threadIdx.x & 31, q = threadIdx.x >> 5;
@@ -375,7 +414,7 @@ __global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a)
 
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
-    dim3 grid((d.N + TS - 1) / TS, (sh.nown + TS - 1) / TS), block(256);
+    dim3 grid(pc_tile_grid((d.N + TS - 1) / TS, (sh.nown + TS - 1) / TS)), block(256);
     switch (mode) {
     case PCW_POCP: hipLaunchKernelGGL(k_walk<PCW_POCP>, grid, block, 0, st, d, sh, a); break;
     case PCW_AF: hipLaunchKernelGGL(k_walk<PCW_AF>, grid, block, 0, st, d, sh, a); break;
