@@ -340,32 +340,38 @@ __global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a)
         if (w0) __syncthreads();
         pc_stage_tile(d, sh, s0, k0, w0, wn, rs, rt);
         __syncthreads();
+        // A pair shares ~3 of its ~80 bitmap words, but some lane of the wave has a hit in almost every word: visiting
+        // inside the word scan would run the (divergent, memory-touching) visit body ~70 times per pair slot.  So the
+        // scan only records which words intersect (branch-free, one 32-bit mask per pair: WCH == 32), and the visits then
+        // loop over the set bits of that mask -- as many iterations as the busiest lane has shared words.  Order stays
+        // ascending.  A thread's four pairs share one row (t under condensed output, s otherwise): its word is read once.
+        uint32_t nz[4] = {0u, 0u, 0u, 0u};
+        for (int i = 0; i < wn; ++i) {
+            const uint64_t common = cond ? rt[f][i] : rs[f][i];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint64_t other = cond ? rs[q + 8 * m][i] : rt[q + 8 * m][i];
+                nz[m] |= ((other & common) != 0 ? 1u : 0u) << i;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (!ok[m]) continue;
             const int ls = ss[m] - s0, lt = kk[m] - k0;
             const uint32_t* rps = d.rankpre + (int64_t)ss[m] * d.Wb + w0;
             const uint32_t* rpt = d.rankpre + (int64_t)tt[m] * d.Wb + w0;
-            // A pair shares ~3 of its ~80 bitmap words, but some lane of the wave has a hit in almost every word: visiting
-            // inside the word scan would run the (divergent, memory-touching) visit body ~70 times per pair slot.  So the
-            // scan only records which words intersect (branch-free, 32 words per mask), and the visits then loop over the
-            // set bits of that mask -- as many iterations as the busiest lane has shared words.  Order stays ascending.
-            for (int wb = 0; wb < wn; wb += 32) {
-                const int we = min(32, wn - wb);
-                uint32_t nz = 0;
-                for (int i = 0; i < we; ++i) nz |= ((rs[ls][wb + i] & rt[lt][wb + i]) != 0 ? 1u : 0u) << i;
-                while (nz) {
-                    const int w = wb + __ffs((int)nz) - 1;
-                    nz &= nz - 1;
-                    const uint64_t sw = rs[ls][w], tw = rt[lt][w];
-                    uint64_t x = sw & tw;
-                    const uint32_t bs = rps[w], bt = rpt[w];
-                    while (x) {
-                        const int b = __ffsll((long long)x) - 1;
-                        x &= x - 1;
-                        const uint64_t below = (1ULL << b) - 1;
-                        pc_visit<MODE>(d, a, acc[m], bs + __popcll(sw & below), bt + __popcll(tw & below), cells, rbytes);
-                    }
+            uint32_t todo = nz[m];
+            while (todo) {
+                const int w = __ffs((int)todo) - 1;
+                todo &= todo - 1;
+                const uint64_t sw = rs[ls][w], tw = rt[lt][w];
+                uint64_t x = sw & tw;
+                const uint32_t bs = rps[w], bt = rpt[w];
+                while (x) {
+                    const int b = __ffsll((long long)x) - 1;
+                    x &= x - 1;
+                    const uint64_t below = (1ULL << b) - 1;
+                    pc_visit<MODE>(d, a, acc[m], bs + __popcll(sw & below), bt + __popcll(tw & below), cells, rbytes);
                 }
             }
         }
