@@ -12,9 +12,18 @@ from phamclust_amd.genome import Genome
 from phamclust_amd.pack import pack_genomes
 
 
+_PAIRWISE_CALLS = 0
+
+
 def _pairwise(metric, source, target, as_distance):
     if not isinstance(source, Genome) or not isinstance(target, Genome):
         raise TypeError(f"cannot compare '{type(source)}' to '{type(target)}'")
+    global _PAIRWISE_CALLS
+    _PAIRWISE_CALLS += 1
+    if _PAIRWISE_CALLS == 1000:                   # each call packs and uploads two genomes: fine for a few, hopeless for a matrix
+        import logging
+        logging.warning("1,000 pairwise METRICS calls so far: every one uploads two genomes to the GPU; "
+                        "matrix_de_novo(genomes, func, cpus) fills a whole matrix in one device pass")
     from phamclust_amd.matrix import get_context
     ctx = get_context()
     ctx.upload(pack_genomes([source, target]))

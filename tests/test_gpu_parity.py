@@ -619,6 +619,45 @@ def test_more_ranks_than_genomes(gpu_ctx, native_built, balanced):
     gpu_ctx.set_shard(0, 1)
 
 
+def test_unsynchronised_fill_survives_reupload(gpu_ctx, native_built):
+    """a fill called without stats returns while its kernels still run on the CALLER's stream and still use the
+    context's work buffers; an upload (or re-shard, or test hook) issued right behind it must wait for them instead of
+    overwriting those buffers.  Fill A asynchronously on a side stream, upload B at once, fill B: both results exact."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    a_pk, b_pk = synth_packed(400, 1200, seed=41), synth_packed(150, 500, seed=42)
+    want_a = O.fill(a_pk, "peq", as_distance=True)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        gpu_ctx.upload(a_pk)
+        out_a = torch.full((a_pk.n_pairs,), -1.0, dtype=torch.float64, device="cuda:0")
+        gpu_ctx.fill_dev("peq", True, out_a.data_ptr(), side.cuda_stream, want_stats=False)      # returns with kernels in flight
+        gpu_ctx.upload(b_pk)                                                                     # must not disturb them
+        got_b = gpu_ctx.fill("peq", as_distance=True)
+        side.synchronize()
+        assert np.array_equal(out_a.cpu().numpy(), want_a)
+        assert np.array_equal(got_b, O.fill(b_pk, "peq", as_distance=True))
+    assert torch.cuda.current_device() == 0
+
+
+def test_fill_borrow_is_the_same_matrix(gpu_ctx, native_built):
+    """pc_fill_borrow: the context's pinned buffer holds exactly what pc_fill returns, is read-only for Python, and is
+    re-used (not re-pinned) by the next call."""
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(300, 900, seed=43)
+    gpu_ctx.upload(packed)
+    for metric in ("jc", "af", "peq"):
+        owned = gpu_ctx.fill(metric, as_distance=True)
+        lent, st = gpu_ctx.fill(metric, as_distance=True, want_stats=True, borrow=True)
+        assert lent.shape == owned.shape and np.array_equal(lent, owned) and st["n_pairs"] == packed.n_pairs
+        assert not lent.flags.writeable
+        with pytest.raises(ValueError):
+            lent[0] = 0.5
+    first = gpu_ctx.fill("gcs", borrow=True).ctypes.data
+    assert gpu_ctx.fill("jc", borrow=True).ctypes.data == first
+
+
 def test_fill_distributed_single_rank(gpu_ctx, native_built):
     """The product's multi-GPU entry point with a 1-rank group: shard -> (no gather) -> device assembly."""
     import torch
