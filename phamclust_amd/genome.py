@@ -33,15 +33,16 @@ class Genome:
         self.phams.setdefault(pham, []).append(translation)
 
     def load(self, fasta):
-        """Load from a single-genome FASTA whose headers carry ``pham=<id>``
-        among ``|``-separated ``key=value`` fields (reference genome.py:67-83)."""
+        """Add every record of a single-genome FASTA file; the pham of a record is the first ``pham=<id>`` item among the
+        ``|``-separated ``key=value`` items of its header (the format ``save`` writes; reference genome.py:67-83).
+        Items are read only up to that one, and each of them must hold exactly one ``=``."""
+        def items(header):
+            for item in header.split("|"):
+                key, value = item.split("=")
+                yield key, value
+
         for header, translation in read_fasta(fasta):
-            pham = None
-            for field in header.split("|"):
-                key, value = field.split("=")
-                if key == "pham":
-                    pham = value
-                    break
+            pham = next((value for key, value in items(header) if key == "pham"), None)
             if pham is None:
                 raise GenomeLoadError("unable to get pham from FASTA header")
             self.add(pham, translation)
