@@ -33,16 +33,16 @@
 enum {
     OP_FMA_F32, OP_PK_FMA_F32, OP_MAX_I32, OP_MAX3_I32, OP_ADD_U32, OP_AND_B32, OP_BCNT, OP_CNDMASK_VCC, OP_CNDMASK_SGPR,
     OP_CMP_VCC, OP_CMP_SGPR, OP_CMP_SDWA_SGPR, OP_ADD_SDWA, OP_ADDC, OP_CNDMASK_DPP_WAVE, OP_MOV_DPP_WAVE, OP_MOV_DPP_ROW,
-    OP_PK_MAX_I16, OP_ADD3_U32, OP_PERM, OP_CNDMASK_VCC_HOISTED, OP_CNDMASK_VCC_E64, OP_MIN_U32, OP_SUB_U32, OP_OR_B32, OP_LSHL_ADD, OP_XOR_B32, OP_MOV_B32, OP_LSHLREV, OP_ASHRREV, OP_MAX_F32, OP_ADD_F32, OP_MUL_U24, OP_MAX_I16, OP_ADD_U16, OP_POPC_MIX, OP_AND_MAX_MIX, OP_CELL, OP_STEP_VCC, OP_STEP_NOVCC, OP_COUNT
+    OP_PK_MAX_I16, OP_ADD3_U32, OP_PERM, OP_CNDMASK_VCC_HOISTED, OP_CNDMASK_VCC_E64, OP_MIN_U32, OP_SUB_U32, OP_OR_B32, OP_LSHL_ADD, OP_XOR_B32, OP_MOV_B32, OP_LSHLREV, OP_ASHRREV, OP_MAX_F32, OP_ADD_F32, OP_MUL_U24, OP_MAX_I16, OP_ADD_U16, OP_POPC_MIX, OP_AND_MAX_MIX, OP_MAX_F64, OP_CELL64, OP_CELL, OP_STEP_VCC, OP_STEP_NOVCC, OP_COUNT
 };
 static const char* kOpName[OP_COUNT] = {
     "v_fma_f32", "v_pk_fma_f32", "v_max_i32", "v_max3_i32", "v_add_u32", "v_and_b32", "v_bcnt_u32_b32", "v_cndmask_b32 (vcc)",
     "v_cndmask_b32 (sgpr pair)", "v_cmp_gt_i32 -> vcc", "v_cmp_gt_i32 -> sgpr pair", "v_cmp_eq_u32_sdwa -> sgpr pair",
     "v_add_u32_sdwa", "v_addc_co_u32 (sgpr carry)", "v_cndmask_b32_dpp wave_shr:1", "v_mov_b32_dpp wave_shr:1",
-    "v_mov_b32_dpp row_shr:1", "v_pk_max_i16", "v_add3_u32", "v_perm_b32", "v_cndmask_b32 (vcc set outside the loop)", "v_cndmask_b32_e64 (vcc as sgpr operand)", "v_min_u32", "v_sub_u32", "v_or_b32", "v_lshl_add_u32", "v_xor_b32", "v_mov_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_max_f32", "v_add_f32", "v_mul_u32_u24", "v_max_i16", "v_add_u16", "popcount tile mix: 32 v_and then 32 v_bcnt (16 chains of 2)", "alternating v_and / v_max_i32",
+    "v_mov_b32_dpp row_shr:1", "v_pk_max_i16", "v_add3_u32", "v_perm_b32", "v_cndmask_b32 (vcc set outside the loop)", "v_cndmask_b32_e64 (vcc as sgpr operand)", "v_min_u32", "v_sub_u32", "v_or_b32", "v_lshl_add_u32", "v_xor_b32", "v_mov_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_max_f32", "v_add_f32", "v_mul_u32_u24", "v_max_i16", "v_add_u16", "popcount tile mix: 32 v_and then 32 v_bcnt (16 chains of 2)", "alternating v_and / v_max_i32", "v_max_f64", "DP cell as 64-bit lexicographic max (11 instr: 4 v_max_f64)",
     "DP cell (15 instr, pc_nw.hip schedule)", "row step: prologue (s_mov vcc + 10 VALU) + 8 cells", "row step: prologue with vcc set outside + 8 cells"};
 // instructions per loop iteration
-static int op_instrs(int op) { return op == OP_CELL ? 15 * 8 : op == OP_STEP_VCC || op == OP_STEP_NOVCC ? 15 * 8 + 11 : op == OP_POPC_MIX ? 128 : 128; }
+static int op_instrs(int op) { return op == OP_CELL ? 15 * 8 : op == OP_STEP_VCC || op == OP_STEP_NOVCC ? 15 * 8 + 11 : op == OP_CELL64 ? 11 * 8 : 128; }
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k_rate(unsigned long long* __restrict__ out, int iters, int seed) {
@@ -59,6 +59,9 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* __restrict__ 
     f2 p[8]; const f2 px = {1.0f, 0.5f}, py = {0.25f, 2.0f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) p[i] = f2{__uint_as_float(r[2 * i] & 0x3fffffffu), __uint_as_float(r[2 * i + 1] & 0x3fffffffu)};
+    double dq[8]; const double dx = __hiloint2double(0x40000000 + (int)(a & 0xffff), (int)b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dq[i] = __hiloint2double(0x40000000 + (int)((r[i] >> 4) & 0xfffff), (int)r[i + 8]);
     unsigned long long t0, t1, q0, q1;
     if constexpr (OP == OP_CNDMASK_VCC_HOISTED || OP == OP_CNDMASK_VCC_E64 || OP == OP_STEP_NOVCC)
         asm volatile("s_mov_b64 vcc, %0" ::"s"(m) : "vcc");          // the loops below contain nothing that writes vcc
@@ -190,6 +193,37 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* __restrict__ 
 #define F(i) "v_and_b32 %" #i ", %16, %17\n\tv_max_i32 %" #i ", %16, %17\n\t"
             asm volatile(REP16_1(F) REP16_1(F) REP16_1(F) REP16_1(F) : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]), "=v"(r[11]), "=v"(r[12]), "=v"(r[13]), "=v"(r[14]), "=v"(r[15]) : "v"(a), "v"(b));
 #undef F
+        } else if constexpr (OP == OP_MAX_F64) {
+            // 8 independent 64-bit register pairs
+#define F(i) "v_max_f64 %" #i ", %8, %" #i "\n\t"
+            asm volatile(R8X(F) : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]), "+v"(dq[4]), "+v"(dq[5]), "+v"(dq[6]), "+v"(dq[7]) : "v"(dx));
+#undef F
+        } else if constexpr (OP == OP_CELL64) {
+            // candidate cell: (score*4 | tag) in the high dword, statistics in the low dword, v_max_f64 as a lexicographic max
+            double HoL = dq[0], EL = dq[1];
+            uint32_t Dhi = r[0], Dlo = r[1];
+            const uint32_t K = 0x10000u, ac = a & 31u, bcn = b, pwn = b ^ a;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                double HoU = dq[2 + (c & 1)], FU = dq[4 + (c & 1)], E, H, T;
+                asm volatile("v_max_f64 %0, %1, %2" : "=v"(E) : "v"(HoL), "v"(EL));
+                asm volatile("v_max_f64 %0, %1, %0" : "+v"(FU) : "v"(HoU));
+                unsigned long long c2; uint32_t Dnhi, Dnlo;
+                const uint32_t HoUhi = (uint32_t)__double2hiint(HoU), HoUlo = (uint32_t)__double2loint(HoU);
+                asm volatile("v_cmp_eq_u32_sdwa %0, %3, %4 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+                             "v_add_u32_sdwa %1, %5, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+                             "v_addc_co_u32 %2, %0, %7, %8, %0"
+                             : "=&s"(c2), "=&v"(Dnhi), "=&v"(Dnlo) : "v"(ac), "v"(bcn), "v"(pwn), "v"(HoUhi), "v"(K), "v"(HoUlo));
+                E = __hiloint2double(__double2hiint(E) | 1, __double2loint(E));
+                FU = __hiloint2double(__double2hiint(FU) | 2, __double2loint(FU));
+                const double D = __hiloint2double((int)Dhi, (int)Dlo);
+                asm volatile("v_max_f64 %0, %1, %2" : "=v"(T) : "v"(D), "v"(FU));
+                asm volatile("v_max_f64 %0, %1, %2" : "=v"(H) : "v"(T), "v"(E));
+                HoU = __hiloint2double((__double2hiint(H) & -4) - 40, __double2loint(H));
+                dq[2 + (c & 1)] = HoU; dq[4 + (c & 1)] = FU;
+                HoL = HoU; EL = E; Dhi = Dnhi; Dlo = Dnlo;
+            }
+            dq[0] = HoL; dq[1] = EL; r[0] = Dhi; r[1] = Dlo;
         } else if constexpr (OP == OP_CNDMASK_SGPR) {
 #define F(i) "v_cndmask_b32 %" #i ", %16, %17, %18\n\t"
             asm volatile(REP16(F) : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]), "=v"(r[11]), "=v"(r[12]), "=v"(r[13]), "=v"(r[14]), "=v"(r[15]) : "v"(a), "v"(b), "s"(m));
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc ^= r[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc ^= (uint32_t)s[i] ^ __float_as_uint(p[i].x) ^ __float_as_uint(p[i].y);
+    for (int i = 0; i < 8; ++i) acc ^= (uint32_t)s[i] ^ __float_as_uint(p[i].x) ^ __float_as_uint(p[i].y) ^ (uint32_t)__double2hiint(dq[i]) ^ (uint32_t)__double2loint(dq[i]);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if ((threadIdx.x & 63) == 0) { out[2 * wave] = t1 - t0; out[2 * wave + 1] = q1 - q0; }
     if (acc == 0x12345u && iters < 0) lds_pad[threadIdx.x] = acc;            // keep everything live
