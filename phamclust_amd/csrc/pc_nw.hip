@@ -180,84 +180,97 @@ __device__ __forceinline__ int pc_shr1(int v) {                        // lane k
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);  // DPP wave_shr:1
 }
 
-// One cell.  In: D, SD (this cell's diagonal candidates), chain (Hol, El, SHl, SEl), row code ac.
-// In/out (in place): column state Hou -> Ho, Fu -> F, SHu -> SH, SFu -> SF.
-// Out: E, SE (chain), and for the next cell Dn = old Hou + sp_next, SDn = old SHu + 0x10000 + (ac == bcn).
-#define PC_CELL_BODY(E_OPENS, F_OPENS, H_GAP, T_PICK, CMP_LINE, NEXT_D, NEXT_SD)                \
-    asm volatile(                                                                               \
-        E_OPENS                                                                                 \
-        F_OPENS                                                                                 \
-        CMP_LINE                                                                                \
-        "v_max_i32 %[E], %[Hol], %[El]\n\t"                                                     \
-        "v_max_i32 %[Fu], %[Hou], %[Fu]\n\t"                                                    \
-        NEXT_D                                                                                  \
-        "v_max3_i32 %[H], %[D], %[E], %[Fu]\n\t"                                                \
-        H_GAP                                                                                   \
-        "v_cmp_eq_u32 %[c4], %[H], %[D]\n\t"                                                    \
-        "v_cndmask_b32 %[SE], %[SEl], %[SHl], %[c0]\n\t"                                        \
-        "v_cndmask_b32 %[SFu], %[SFu], %[SHu], %[c1]\n\t"                                       \
-        NEXT_SD                                                                                 \
-        "v_add_u32 %[Hou], -10, %[H]\n\t"                                                       \
-        T_PICK                                                                                  \
-        "v_cndmask_b32 %[SHu], %[T], %[SD], %[c4]\n\t"                                          \
-        : [E] "=&v"(E), [SE] "=&v"(SE), [H] "=&v"(H), [T] "=&v"(T),                                              \
-          [Dn] "=&v"(Dn), [SDn] "=&v"(SDn), [Hou] "+v"(Hou), [Fu] "+v"(Fu), [SHu] "+v"(SHu), [SFu] "+v"(SFu),    \
-          [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4)                         \
-        : [D] "v"(D), [SD] "v"(SD), [Hol] "v"(Hol), [El] "v"(El), [SHl] "v"(SHl), [SEl] "v"(SEl), [ac] "v"(ac),  \
-          [bcn] "v"(bcn), [pwn] "v"(pwn), [K] "v"(K))
+// ---------------------------------------------------------------------------------
+// The DP cell as a LEXICOGRAPHIC MAX on 64-bit words (r02; the r01 cell carried scores and statistics in separate
+// registers and needed a compare + select for every statistic it moved: 15 instructions).
+//
+// Every DP value travels as one 64-bit word  V = (hi, lo):
+//   hi = 0x40000000 + 4 * score + tag     (score = the anti-diagonal-biased score; tag in the two low bits)
+//   lo = n_ident | n_diag << 16           (the path statistics, as before)
+// 0x20000000 <= hi < 0x50000000 for every score this kernel can meet (-inf is -2^27), so V read as an IEEE double is a
+// positive NORMAL number, and for positive doubles "greater" is the unsigned order of the 63 bits: v_max_f64 returns,
+// bit for bit, the operand with the larger score -- on equal scores the one with the larger tag -- and the statistics
+// ride along in the low mantissa bits for free.  v_max_f64 issues at the same 4 clocks as v_max_i32
+// (profiles/valu_issue_rate.json).  The tags ARE the tie rules:
+//   E = max(Ho_left [tOE], E_left [tE])          ties -> the larger tag: extend (tE > tOE) or open (tOE > tE)
+//   F = max(Ho_up   [tOF], F_up   [tF])
+//   H = max(D [3], F [tF], E [tE])               DIAG first, then the gap state with the larger tag
+// after each max the result is re-tagged for its next use ((hi & ~3) | tag: one v_and_or_b32), and Ho = H - 10 becomes
+// (hi & ~3) - 40 + tOF.  11 VALU instructions per cell (4 x v_max_f64, 2 x v_and_or, v_and, v_add, and for the next cell's
+// diagonal term v_cmp_eq_sdwa, v_add_sdwa, v_addc), against 15.  Six of the eight tie rules are a consistent order of
+// (tO, tE, tF); rules 3 and 4 ask for tOE > tE > tF > tOF resp. tOF > tF > tE > tOE, i.e. two different "open" tags, which
+// costs them one more v_add per cell.
+// ---------------------------------------------------------------------------------
+#define PC_HI0 0x40000000                                  // hi of score 0, tag 0
+#define PC_S4(x) (PC_HI0 + 4 * (x))                        // hi of (anti-diagonal-biased) score x, tag 0
+#define PC_NEG4 PC_S4(-(1 << 27))                          // "-infinity": survives +95 per diagonal step for 65,535 steps
 
-#define PC_CMP(SEL) "v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:BYTE_0 src1_sel:" SEL "\n\t"
-#define PC_NEXT_D(SEL) "v_add_u32_sdwa %[Dn], %[pwn], %[Hou] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t"
-#define PC_NEXT_SD "v_addc_co_u32 %[SDn], %[c2], %[K], %[SHu], %[c2]\n\t"
-
-// The tie-rule table of the asm cell: the only instructions that differ between the 8 rules.
-#define PC_TIE_E_EXTENDS "v_cmp_gt_i32 %[c0], %[Hol], %[El]\n\t"      /* E opens iff open > extend  (rule bit 1 = 0) */
-#define PC_TIE_E_OPENS "v_cmp_ge_i32 %[c0], %[Hol], %[El]\n\t"        /* E opens iff open >= extend (rule bit 1 = 1) */
-#define PC_TIE_F_EXTENDS "v_cmp_gt_i32 %[c1], %[Hou], %[Fu]\n\t"      /* rule bit 2 = 0 */
-#define PC_TIE_F_OPENS "v_cmp_ge_i32 %[c1], %[Hou], %[Fu]\n\t"        /* rule bit 2 = 1 */
-#define PC_TIE_H_DEL_FIRST "v_cmp_eq_u32 %[c3], %[H], %[Fu]\n\t"      /* H == F takes F's stats, else E's (rule bit 0 = 0) */
-#define PC_TIE_T_DEL_FIRST "v_cndmask_b32 %[T], %[SE], %[SFu], %[c3]\n\t"
-#define PC_TIE_H_INS_FIRST "v_cmp_eq_u32 %[c3], %[H], %[E]\n\t"       /* H == E takes E's stats, else F's (rule bit 0 = 1) */
-#define PC_TIE_T_INS_FIRST "v_cndmask_b32 %[T], %[SFu], %[SE], %[c3]\n\t"
-
-template <int NEXT_BYTE, int RULE>   // NEXT_BYTE: byte of pwn holding the next cell's score; -1: last cell of the lane
-__device__ __forceinline__ void pc_cell_asm(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl,
-                                            int& Hou, int& Fu, uint32_t& SHu, uint32_t& SFu, int& E, uint32_t& SE,
-                                            int& Dn, uint32_t& SDn, int ac, int bcn, uint32_t pwn, uint32_t K) {
-    int H; uint32_t T;
-    unsigned long long c0, c1, c2, c3, c4;
-#define PC_CELL_RULE(EO, FO, HG, TP)                                                                      \
-    do {                                                                                                  \
-        if constexpr (NEXT_BYTE == 0) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_0"), PC_NEXT_D("BYTE_0"), PC_NEXT_SD);      \
-        else if constexpr (NEXT_BYTE == 1) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_1"), PC_NEXT_D("BYTE_1"), PC_NEXT_SD); \
-        else if constexpr (NEXT_BYTE == 2) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_2"), PC_NEXT_D("BYTE_2"), PC_NEXT_SD); \
-        else if constexpr (NEXT_BYTE == 3) PC_CELL_BODY(EO, FO, HG, TP, PC_CMP("BYTE_3"), PC_NEXT_D("BYTE_3"), PC_NEXT_SD); \
-        else { PC_CELL_BODY(EO, FO, HG, TP, "", "", ""); Dn = 0; SDn = 0; }                                                  \
-    } while (0)
+template <int RULE>
+struct PcTag {                                             // the TIE-RULE TABLE of the systolic kernel (rule bits: see pc_cell above)
     static_assert(RULE >= 0 && RULE < 8, "tie rule");
-    if constexpr (RULE == 0) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_EXTENDS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
-    else if constexpr (RULE == 1) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_EXTENDS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
-    else if constexpr (RULE == 2) PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_EXTENDS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
-    else if constexpr (RULE == 3) PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_EXTENDS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
-    else if constexpr (RULE == 4) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_OPENS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
-    else if constexpr (RULE == 5) PC_CELL_RULE(PC_TIE_E_EXTENDS, PC_TIE_F_OPENS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
-    else if constexpr (RULE == 6) PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_OPENS, PC_TIE_H_DEL_FIRST, PC_TIE_T_DEL_FIRST);
-    else PC_CELL_RULE(PC_TIE_E_OPENS, PC_TIE_F_OPENS, PC_TIE_H_INS_FIRST, PC_TIE_T_INS_FIRST);
-#undef PC_CELL_RULE
+    static constexpr bool ins_first = (RULE & 1) != 0, e_opens = (RULE & 2) != 0, f_opens = (RULE & 4) != 0;
+    static constexpr bool cyclic = RULE == 3 || RULE == 4;
+    //                              rule:   0  1  2  3  4  5  6  7
+    static constexpr int kE[8]   =        { 1, 2, 0, 2, 1, 2, 0, 1 };     // tag of a stored E (gap in query, INS)
+    static constexpr int kF[8]   =        { 2, 1, 2, 1, 2, 0, 1, 0 };     // tag of a stored F (gap in ref, DEL)
+    static constexpr int kOE[8]  =        { 0, 0, 1, 3, 0, 1, 2, 2 };     // tag of Ho where E's max reads it
+    static constexpr int kOF[8]  =        { 0, 0, 1, 0, 3, 1, 2, 2 };     // tag of Ho where F's max reads it (the stored one)
+    static constexpr int tD = 3, tE = kE[RULE], tF = kF[RULE], tOE = kOE[RULE], tOF = kOF[RULE];
+    static_assert((tE > tOE) != e_opens && (tF > tOF) != f_opens && (tE > tF) == ins_first && tE != tF, "tags do not spell the rule");
+    static_assert(tE < tD && tF < tD && (cyclic || tOE == tOF), "tags");
+};
+
+__device__ __forceinline__ double pc_pack(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ uint32_t pc_hi(double v) { return (uint32_t)__double2hiint(v); }
+__device__ __forceinline__ uint32_t pc_lo(double v) { return (uint32_t)__double2loint(v); }
+__device__ __forceinline__ double pc_retag(double v, uint32_t tag) { return pc_pack((pc_hi(v) & ~3u) | tag, pc_lo(v)); }
+
+// One cell.  In: D (this cell's diagonal candidate, tag 3), chain values HoL [tag tOF] and EL [tE], row code ac.
+// In/out (in place): column state Hou -> Ho, Fu -> F.  Out: E (chain), and for the next cell Dn = old Hou + score of the
+// next cell (+ 3 - tOF, folded into the profile byte) with statistics old Hou's + 0x10000 + (ac == bcn).
+// The first block is asm because of its SDWA forms and because v_cmp's SGPR result must not be read by v_addc sooner than
+// two instructions later (gfx950; nothing pads inside asm): the two independent v_max_f64 sit in between.
+template <int NEXT_BYTE, int RULE>
+__device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, double& Hou, double& Fu, double& E, double& Dn,
+                                          uint32_t ac, uint32_t bcn, uint32_t pwn, uint32_t K) {
+    using T = PcTag<RULE>;
+    if constexpr (T::cyclic) HoL = pc_pack(pc_hi(HoL) + (uint32_t)(T::tOE - T::tOF), pc_lo(HoL));
+    const uint32_t ohi = pc_hi(Hou), olo = pc_lo(Hou);
+    uint32_t dn_hi = 0, dn_lo = 0;
+    unsigned long long c2;
+#define PC_CELL64_A(SEL)                                                                                               \
+    asm("v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:BYTE_0 src1_sel:" SEL "\n\t"                                  \
+        "v_max_f64 %[E], %[HoL], %[EL]\n\t"                                                                            \
+        "v_max_f64 %[Fu], %[Hou], %[Fu]\n\t"                                                                           \
+        "v_add_u32_sdwa %[dh], %[pwn], %[ohi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
+        "v_addc_co_u32 %[dl], %[c2], %[K], %[olo], %[c2]"                                                              \
+        : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo), [c2] "=&s"(c2)                            \
+        : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [ac] "v"(ac), [bcn] "v"(bcn),  \
+          [pwn] "v"(pwn), [K] "v"(K))
+    if constexpr (NEXT_BYTE == 0) PC_CELL64_A("BYTE_0");
+    else if constexpr (NEXT_BYTE == 1) PC_CELL64_A("BYTE_1");
+    else if constexpr (NEXT_BYTE == 2) PC_CELL64_A("BYTE_2");
+    else if constexpr (NEXT_BYTE == 3) PC_CELL64_A("BYTE_3");
+    else asm("v_max_f64 %[E], %[HoL], %[EL]\n\tv_max_f64 %[Fu], %[Hou], %[Fu]" : [E] "=&v"(E), [Fu] "+v"(Fu) : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou));
+#undef PC_CELL64_A
+    E = pc_retag(E, T::tE);
+    Fu = pc_retag(Fu, T::tF);
+    double H;
+    asm("v_max_f64 %0, %1, %2\n\tv_max_f64 %0, %0, %3" : "=&v"(H) : "v"(D), "v"(Fu), "v"(E));
+    Hou = pc_pack((pc_hi(H) & ~3u) + (uint32_t)(T::tOF - 40), pc_lo(H));
+    Dn = pc_pack(dn_hi, dn_lo);
 }
 
 template <int W, int C, int RULE>
 struct PcRow {          // compile-time unrolled sweep over the lane's W columns
-    static __device__ __forceinline__ void run(int D, uint32_t SD, int Hol, int El, uint32_t SHl, uint32_t SEl, int (&Hou)[W],
-                                               int (&Fu)[W], uint32_t (&SHu)[W], uint32_t (&SFu)[W], const uint32_t (&bc)[(W + 3) / 4],
-                                               const uint32_t (&pw)[(W + 3) / 4], int ac, uint32_t K, int& E_out, uint32_t& SE_out) {
-        int E, Dn; uint32_t SE, SDn;
+    static __device__ __forceinline__ void run(double D, double HoL, double EL, double (&Hou)[W], double (&Fu)[W],
+                                               const uint32_t (&bc)[(W + 3) / 4], const uint32_t (&pw)[(W + 3) / 4], uint32_t ac, uint32_t K,
+                                               double& E_out) {
+        double E, Dn;
         constexpr int NB = (C + 1 < W) ? ((C + 1) & 3) : -1;
-        pc_cell_asm<NB, RULE>(D, SD, Hol, El, SHl, SEl, Hou[C], Fu[C], SHu[C], SFu[C], E, SE, Dn, SDn, ac,
-                        (int)bc[(C + 1 < W) ? ((C + 1) >> 2) : 0], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
-        if constexpr (C + 1 < W)
-            PcRow<W, C + 1, RULE>::run(Dn, SDn, Hou[C], E, SHu[C], SE, Hou, Fu, SHu, SFu, bc, pw, ac, K, E_out, SE_out);
-        else { E_out = E; SE_out = SE; }
+        pc_cell64<NB, RULE>(D, HoL, EL, Hou[C], Fu[C], E, Dn, ac, bc[(C + 1 < W) ? ((C + 1) >> 2) : 0], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
+        if constexpr (C + 1 < W) PcRow<W, C + 1, RULE>::run(Dn, Hou[C], E, Hou, Fu, bc, pw, ac, K, E_out);
+        else E_out = E;
     }
 };
 
@@ -268,23 +281,25 @@ __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// SH of column slot `want` (wave-uniform, runtime) picked with compile-time register indices only: a loop over c
-// with `if (c == want)` lets the compiler keep a scratch-memory copy of the whole array up to date in the hot loop.
+// Statistics (lo) of column slot `want` (wave-uniform, runtime) picked with compile-time register indices only: a loop
+// over c with `if (c == want)` lets the compiler keep a scratch-memory copy of the whole array up to date in the hot loop.
 template <int W, int C>
 struct PcPick {
-    static __device__ __forceinline__ uint32_t get(const uint32_t (&SHu)[W], int want) {
-        if constexpr (C + 1 < W) { const uint32_t rest = PcPick<W, C + 1>::get(SHu, want); return want == C ? SHu[C] : rest; }
-        else return SHu[C];
+    static __device__ __forceinline__ uint32_t get(const double (&Hou)[W], int want) {
+        if constexpr (C + 1 < W) { const uint32_t rest = PcPick<W, C + 1>::get(Hou, want); return want == C ? pc_lo(Hou[C]) : rest; }
+        else return pc_lo(Hou[C]);
     }
 };
 
 // Lanes whose entry is the virtual row -1 (mask m, an SGPR pair written by the step prologue's SDWA compare) forget
-// the previous row: Hou := Fu := -inf.
-template <int W, int C>
+// the previous row: Hou := Fu := -inf (each with the tag its reader expects).
+template <int W, int C, int RULE>
 struct PcReset {
-    static __device__ __forceinline__ void run(int (&Hou)[W], int (&Fu)[W], int vneg, unsigned long long m) {
-        asm volatile("v_cndmask_b32 %0, %0, %2, %3\n\tv_cndmask_b32 %1, %1, %2, %3" : "+v"(Hou[C]), "+v"(Fu[C]) : "v"(vneg), "s"(m));
-        if constexpr (C + 1 < W) PcReset<W, C + 1>::run(Hou, Fu, vneg, m);
+    static __device__ __forceinline__ void run(double (&Hou)[W], double (&Fu)[W], uint32_t neg_o, uint32_t neg_f, unsigned long long m) {
+        uint32_t h = pc_hi(Hou[C]), f = pc_hi(Fu[C]);
+        asm volatile("v_cndmask_b32 %0, %0, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %4" : "+v"(h), "+v"(f) : "v"(neg_o), "v"(neg_f), "s"(m));
+        Hou[C] = pc_pack(h, pc_lo(Hou[C])); Fu[C] = pc_pack(f, pc_lo(Fu[C]));
+        if constexpr (C + 1 < W) PcReset<W, C + 1, RULE>::run(Hou, Fu, neg_o, neg_f, m);
     }
 };
 
@@ -314,7 +329,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] local row whose record holds the window start
     uint32_t* ring = seg_cur + PC_MAX_SEG;                           // [16][PC_WIN] staged stream entries
     uint32_t* prof = smem + 144 + PC_WAVES * PC_WREG;                // [G][24][ND], shared by the 4 waves
-    for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(c_b62[i / 24][i % 24] + 12);   // S + 12: see the bias note
+    // profile bytes: 4 * (S + 12) (the bias note above, scaled to the score field of `hi`) + what turns the stored Ho's tag into DIAG's
+    for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
 
     const PcTask tk = tasks[blockIdx.x];
     const int lb = d.gene_len[tk.gene];
@@ -380,11 +396,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     for (int s2 = 0; s2 < nseg; ++s2) T = max(T, (int)seg_len[s2]);
     T = __builtin_amdgcn_readfirstlane(T) + G - 1;
 
-    int Hou[W], Fu[W]; uint32_t SHu[W], SFu[W];
+    using TG = PcTag<RULE>;
+    double Hou[W], Fu[W];                            // previous row of my W columns: Ho [tag tOF] and F [tag tF], statistics in the low halves
 #pragma unroll
-    for (int c = 0; c < W; ++c) { Hou[c] = PC_NEG; Fu[c] = PC_NEG; SHu[c] = 0; SFu[c] = 0; }
-    int o_E = PC_NEG; uint32_t o_SE = 0;            // my last column's E / SE of the previous step
-    int p_Hol = PC_NEG; uint32_t p_SHl = 0;         // what I received last step (diagonal of column 0)
+    for (int c = 0; c < W; ++c) { Hou[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u); Fu[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tF), 0u); }
+    double o_E = pc_pack((uint32_t)(PC_NEG4 + TG::tE), 0u);        // my last column's E of the previous step
+    double p_HoL = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u);     // what I received last step (diagonal of column 0)
     int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
     const int half = lane >> 5, hl = lane & 31;
@@ -445,36 +462,40 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
     uint32_t pw[ND];
     load_prof(a, pw);
     const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out);
-    const int v_hb = -22, v_neg = PC_NEG; const uint32_t v_zero = 0;   // boundary values the head lanes take (VGPR operands)
+    // boundary values the head lanes take (VGPR operands): Ho^(i,-1) = -22, E = -inf, statistics 0; and what a lane starting an alignment resets to
+    const uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0;
+    const uint32_t v_nego = (uint32_t)(PC_NEG4 + TG::tOF), v_negf = (uint32_t)(PC_NEG4 + TG::tF), v_negd = (uint32_t)(PC_NEG4 + TG::tD),
+                   v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
 
     // One row step.  `a`/`pw` are this step's stream entry and profile strip; `a_nxt`/`pw_nxt` receive the next step's.
     auto step = [&](int t, const bool even, uint32_t a, const uint32_t (&pw)[ND], uint32_t& a_nxt, uint32_t (&pw_nxt)[ND]) {
         if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         // Step prologue, 10 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
         // k-1's value (DPP wave_shr:1 on src0, executed with every lane active), head lanes (vcc) take src1 = their
-        // boundary value instead: the next entry from the ring, Ho^(i,-1) = -22, E = -inf, stats 0.  The flag
-        // tests and the first cell's diagonal term use SDWA byte selects on the raw entry.  K.BYTE_2 == 1.
-        int Hol, El, D0; uint32_t SHl, SEl, SD0;
+        // boundary value instead: the next entry from the ring, Ho^(i,-1) = -22, E = -inf, stats 0.  Ho and E are 64-bit
+        // words now, so the four value exchanges are their two halves each -- the same count as the r01 kernel's
+        // (Ho, E, SH, SE).  The flag tests and the first cell's diagonal term use SDWA byte selects on the raw entry.
+        // K.BYTE_2 == 1.
+        uint32_t HoL_hi, HoL_lo, EL_hi, EL_lo, D0_hi, D0_lo;
         unsigned long long rstm, lastm, c2;
-        const int Hod = p_Hol; const uint32_t SHd = p_SHl;
         asm volatile(
             "s_nop 1\n\t"                                                   // VALU (previous step's cells) -> DPP read: 2 wait states
             "s_mov_b64 vcc, %[hm]\n\t"
             "v_cmp_eq_u32_sdwa %[c2], %[a], %[bc0] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
             "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_cndmask_b32_dpp %[Hol], %[Hw], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_cndmask_b32_dpp %[El], %[oE], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_cndmask_b32_dpp %[SHl], %[SHw], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_mov_b32_dpp %[SEl], %[oSE] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // head: E opens, SE := SHl
+            "v_cndmask_b32_dpp %[Hh], %[Hwh], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // head: E = -inf never wins, its statistics are never read
             "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
             "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-            "v_add_u32_sdwa %[D0], %[pw0], %[Hod] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
-            "v_addc_co_u32 %[SD0], %[c2], %[K], %[SHd], %[c2]\n\t"
-            : [an] "=&v"(a_nxt), [Hol] "=&v"(Hol), [El] "=&v"(El), [SHl] "=&v"(SHl), [SEl] "=&v"(SEl), [D0] "=&v"(D0),
-              [SD0] "=&v"(SD0), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
-            : [hm] "s"(headm), [a] "v"(a), [en] "v"(e_nxt), [Hw] "v"(Hou[W - 1]), [hb] "v"(v_hb), [oE] "v"(o_E), [neg] "v"(v_neg),
-              [SHw] "v"(SHu[W - 1]), [zero] "v"(v_zero), [oSE] "v"(o_SE), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
-              [Hod] "v"(Hod), [SHd] "v"(SHd)
+            "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+            "v_addc_co_u32 %[D0l], %[c2], %[K], %[Hodl], %[c2]\n\t"
+            : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
+              [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
+            : [hm] "s"(headm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+              [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
+              [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
             : "vcc");
         load_prof(a_nxt, pw_nxt);
         if (even) {                                                       // the head's entries for steps t+2 and t+3
@@ -483,16 +504,17 @@ __global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const Pc
         } else e_nxt = e_b;
         if (rstm != 0) {                                                  // some lane starts an alignment this step (virtual row -1)
             const unsigned long long hr = rstm & headm;
-            PcReset<W, 0>::run(Hou, Fu, v_neg, rstm);
-            asm volatile("v_cndmask_b32 %0, %0, %2, %3\n\tv_cndmask_b32 %1, %1, -12, %4"      // D := -inf; head: Ho^(-1,-1) = -12
-                         : "+v"(D0), "+v"(Hol) : "v"(v_neg), "s"(rstm), "s"(hr));
+            PcReset<W, 0, RULE>::run(Hou, Fu, v_nego, v_negf, rstm);
+            asm volatile("v_cndmask_b32 %0, %0, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %5"        // D := -inf; head: Ho^(-1,-1) = -12
+                         : "+v"(D0_hi), "+v"(HoL_hi) : "v"(v_negd), "v"(v_h00), "s"(rstm), "s"(hr));
         }
-        p_Hol = Hol; p_SHl = SHl;
-        PcRow<W, 0, RULE>::run(D0, SD0, Hol, El, SHl, SEl, Hou, Fu, SHu, SFu, bc, pw, (int)a, K, o_E, o_SE);
+        const double HoL = pc_pack(HoL_hi, HoL_lo);
+        p_HoL = HoL;
+        PcRow<W, 0, RULE>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, a, K, o_E);
         if ((lastm & outm) != 0) {                                        // a row's last cell left the lane holding column lb-1
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
             if ((a & PCF_LAST) && is_out) {
-                const uint32_t st = PcPick<W, 0>::get(SHu, c_out);
+                const uint32_t st = PcPick<W, 0>::get(Hou, c_out);
                 res[bucket_dest ? bucket_dest[tk.begin + task_row(out_r)] : (uint32_t)(tk.begin + task_row(out_r))] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
                 out_r += nseg;
             }
