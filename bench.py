@@ -13,10 +13,10 @@ packed genomes already resident in HBM.  With N ranks the SAME matrix is filled 
 Extra objects on that line:
   roofline      the dominant kernels (the K4 alignment launches of one fill, timed with HIP
                 events on the stream they run on, inside the library).  The recurrence is bound
-                by 32-bit integer VALU issue: every instruction class of the 15-instruction DP
-                cell retires one wave64 instruction per 4 clocks per SIMD (measured:
+                by VALU issue: every instruction class of the 11-instruction DP cell (v_max_f64
+                included) retires one wave64 instruction per 4 clocks per SIMD (measured:
                 profiles/valu_issue_rate.json), so peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
-                lane-ops/s and achieved = 15 x DP cells computed / kernel time.  `hbm` inside it
+                lane-ops/s and achieved = 11 x DP cells computed / kernel time.  `hbm` inside it
                 is the figure the north star asks for: algorithmic bytes = sum(la+lb) residues
                 read + 16 B per alignment (bucket entry in, result out) against 8 TB/s -- small
                 by construction.  `traffic` = HBM bytes of those launches from rocprofv3 PMC
@@ -246,19 +246,20 @@ def main():
         per_gpu_time = ms_align / 1e3
         hbm_achieved = algo_bytes / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
         gcups = n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
-        # The bound that binds: 32-bit integer VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: a wave64 VALU
-        # instruction of every class the DP cell uses (v_cmp -> SGPR, v_cndmask, v_max_i32, v_max3, SDWA, v_addc) holds its
-        # SIMD for 4 clocks at any occupancy (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json; only plain
-        # add/sub/and/or/xor/mov, f32 add/fma and the 16-bit max/add go at 2), and the hand-scheduled cell is 15 of them.
-        instr_per_cell = 15
+        # The bound that binds: VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: a wave64 VALU instruction of every
+        # class the DP cell uses (v_max_f64, v_and_or_b32, SDWA forms, v_addc, and a mixed stream of anything) holds its SIMD
+        # for 4 clocks at any occupancy (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json; only unmixed runs of plain
+        # add/sub/and/or/xor/mov, f32 add/fma and the 16-bit max/add go at 2), and the cell is 11 of them: four v_max_f64
+        # acting as lexicographic (score, tie-break tag, path statistics) maxima (r01's cell was 15).
+        instr_per_cell = 11
         lane_ops_peak = 256 * 4 * 16 * 2.4e9
         lane_ops = instr_per_cell * gcups * 1e9
         line["roofline"] = {
-            "bound": "valu", "achieved": lane_ops / 1e12, "peak": lane_ops_peak / 1e12, "unit": "Tlane-op/s (int32 VALU)",
+            "bound": "valu", "achieved": lane_ops / 1e12, "peak": lane_ops_peak / 1e12, "unit": "Tlane-op/s (VALU)",
             "frac": lane_ops / lane_ops_peak, "traffic": None,
             "kernel": "k_nw_systolic<W,RULE> (all variant launches of one fill, per GPU)",
             "instr_per_cell": instr_per_cell, "peak_gcups": lane_ops_peak / instr_per_cell / 1e9, "achieved_gcups": gcups,
-            "issue_rate_source": "profiles/valu_issue_rate.json (4.0-4.15 clk per wave64 instruction per SIMD for every class in the cell)",
+            "issue_rate_source": "profiles/valu_issue_rate.json (4.0-4.15 clk per wave64 instruction per SIMD for every class in the cell, v_max_f64 included)",
             "ms_kernels_per_fill": ms_align, "n_alignments": n_aln, "dp_cells": n_cells,
             # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
             "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells, "gcups_per_gpu": gcups,

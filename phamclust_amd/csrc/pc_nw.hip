@@ -9,7 +9,7 @@
 //   E(i,j) = max(H(i,j-1)-11, E(i,j-1)-1)   ties -> extend      (gap in query, "INS")
 //   F(i,j) = max(H(i-1,j)-11, F(i-1,j)-1)   ties -> extend      (gap in ref,   "DEL")
 //   H(i,j) = max(H(i-1,j-1)+S, E, F)        ties -> DIAG, then F, then E
-// Those three tie-breaks are rule 0 of the TIE-RULE TABLE below (PC_TIE_*): parasail's source is not available
+// Those three tie-breaks are rule 0 of the TIE-RULE TABLE below (PcTag / pc_cell): parasail's source is not available
 // (SURVEY.md 8c), so each is a switch -- every kernel exists for all 8 combinations and pc_set_tie_rule() picks
 // one at run time (the CPU checker under tests/ has the same switch).  tests/golden/tie_sensitivity.json holds
 // what each switch is worth.
@@ -17,7 +17,9 @@
 // column and F of the next row consume; the substitution profile is biased by +11.
 // Stats are one u32: n_ident in the low half, n_diag in the high half, so the diagonal
 // update is a single add-with-carry: SD = SHdiag + 0x10000 + (a == b).
-// Integer VALU work: no MFMA (there is no dense contraction in this recurrence).
+// In the systolic kernel score, tie-break tag and stats travel as ONE 64-bit word and v_max_f64 is the
+// lexicographic max over them (see "The DP cell as a LEXICOGRAPHIC MAX" below).
+// VALU work: no MFMA (there is no dense contraction in this recurrence).
 #include <cstdlib>
 #include <cstring>
 
@@ -164,10 +166,10 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 //   E^(i,j) = max(Ho^(i,j-1), E^(i,j-1)),  F^(i,j) = max(Ho^(i-1,j), F^(i-1,j)),  Ho^ = H^ - 10,
 //   H^(i,j) = max3(Ho^(i-1,j-1) + S + 12, E^, F^); all candidates of one cell share the bias, so every
 // comparison and tie-break is unchanged, and the boundaries become constants (Ho^(i,-1) = Ho^(-1,j) = -22,
-// Ho^(-1,-1) = -12).  The DP cell is hand-scheduled (pc_cell_asm): 15 VALU instructions, column state updated
-// in place, the NEXT cell's diagonal term computed from the old column state before it is
-// overwritten (so no register copies), and every VALU-written SGPR pair read >= 2
-// instructions later (gfx950 needs 2 wait states there; hipcc pads nothing inside asm).
+// Ho^(-1,-1) = -12).  The DP cell (pc_cell64) is 11 VALU instructions, column state updated in place, the NEXT
+// cell's diagonal term computed from the old column state before it is overwritten (so no register copies), and
+// the one VALU-written SGPR pair read >= 2 instructions later (gfx950 needs 2 wait states there; hipcc pads
+// nothing inside asm).
 // ---------------------------------------------------------------------------------
 // Stream entry (u32): byte 0 residue code | byte 1 flags | high half = byte offset of the code's profile row
 // inside a lane's strip table (so the profile address is one SDWA add, and each flag one SDWA compare).
@@ -309,8 +311,10 @@ typedef uint32_t pc_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const pc_u32x2 pc_lds_u32x2;
 typedef __attribute__((address_space(3))) const pc_u32x4 pc_lds_u32x4;
 
+// (second launch bound = waves per SIMD the compiler must leave room for: W = 48 needs 257 registers left to itself, one more
+// than the 256 that let two waves share a SIMD)
 template <int W, int RULE>
-__global__ __launch_bounds__(64 * PC_WAVES) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+__global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
                                                                const uint32_t* __restrict__ bucket_dest,
                                                                uint2* __restrict__ res) {
