@@ -626,8 +626,8 @@ def test_unsynchronised_fill_survives_reupload(gpu_ctx, native_built):
     import torch
     from phamclust_amd.synth import synth_packed
     O = _oracle()
-    a_pk, b_pk = synth_packed(400, 1200, seed=41), synth_packed(150, 500, seed=42)
-    want_a = O.fill(a_pk, "peq", as_distance=True)
+    a_pk, b_pk = synth_packed(260, 900, seed=41), synth_packed(110, 400, seed=42)
+    want_a, want_b = O.fill(a_pk, "peq", as_distance=True), O.fill(b_pk, "peq", as_distance=True)
     side = torch.cuda.Stream()
     for _ in range(3):
         gpu_ctx.upload(a_pk)
@@ -637,7 +637,7 @@ def test_unsynchronised_fill_survives_reupload(gpu_ctx, native_built):
         got_b = gpu_ctx.fill("peq", as_distance=True)
         side.synchronize()
         assert np.array_equal(out_a.cpu().numpy(), want_a)
-        assert np.array_equal(got_b, O.fill(b_pk, "peq", as_distance=True))
+        assert np.array_equal(got_b, want_b)
     assert torch.cuda.current_device() == 0
 
 
