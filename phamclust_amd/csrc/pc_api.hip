@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <memory>
+#include <new>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -55,6 +57,13 @@ template <class F> void parallel_chunks(int64_t n, F fn) {
     const int64_t per = (n + nt - 1) / nt;
     for (int t = 0; t < nt; ++t) th.emplace_back([=] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
     for (auto& x : th) x.join();
+}
+
+static int upload_raw(DevBuf& b, const void* p, size_t bytes) {
+    int rc = b.ensure(std::max<size_t>(bytes, 16));
+    if (rc != PC_OK) return rc;
+    if (bytes) PC_HIP(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice));
+    return PC_OK;
 }
 
 template <class T> int upload_vec(DevBuf& b, const std::vector<T>& v) {
@@ -302,16 +311,24 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     }
     lap("entries, rank table");
     // encoded residues (16-byte padded per gene) and a 64-bit hash of each gene's codes, on several host threads
-    std::vector<uint8_t> codes((size_t)std::max<int64_t>(code_bytes, 16));
+    // (not a std::vector: value-initialising ~10^8 bytes on one thread cost as much as encoding them on sixteen; the worker
+    // threads below are the first to touch their part)
+    const size_t codes_size = (size_t)std::max<int64_t>(code_bytes, 16);
+    std::unique_ptr<uint8_t[]> codes(new (std::nothrow) uint8_t[codes_size]);
+    if (!codes) { pc_set_error("pc_upload: out of host memory (%zu bytes of residue codes)", codes_size); return PC_ERR_LIMIT; }
+    if (code_bytes < 16) memset(codes.get(), PC_PADCODE, 16);
     std::vector<uint64_t> ghash(std::max(G, 1));
     uint8_t lut[256]; build_code_lut(lut);
     parallel_chunks(G, [&](int64_t k0, int64_t k1) {
         for (int64_t k = k0; k < k1; ++k) {
             const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
             const int len = gene_len[k], padded = (len + 15) & ~15;
-            uint64_t h = 0x9e3779b97f4a7c15ULL ^ (uint64_t)len;
-            for (int i = 0; i < len; ++i) { const uint8_t cd = lut[src[i]]; dst[i] = cd; h = (h ^ cd) * 0x100000001b3ULL; }
+            for (int i = 0; i < len; ++i) dst[i] = lut[src[i]];
             for (int i = len; i < padded; ++i) dst[i] = (uint8_t)PC_PADCODE;
+            // hash of the padded codes, 8 bytes per multiply (a byte-wise multiply chain cost as much as the encoding itself);
+            // equal hash and length are confirmed by comparing the codes, so only its spread matters
+            uint64_t h = 0x9e3779b97f4a7c15ULL ^ (uint64_t)len;
+            for (int i = 0; i < padded; i += 8) { uint64_t w; memcpy(&w, dst + i, 8); h = (h ^ w) * 0x9fb21c651e98df25ULL; h ^= h >> 32; }
             ghash[k] = h ^ (h >> 29);
         }
     });
@@ -407,7 +424,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     std::vector<int64_t> tlen(g->tlen, g->tlen + N);
     if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
         (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
-        (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_vec(c->b_codes, codes)) || (rc = upload_vec(c->b_nph, nph)) ||
+        (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_raw(c->b_codes, codes.get(), codes_size)) || (rc = upload_vec(c->b_nph, nph)) ||
         (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
         (rc = upload_vec(c->b_q_class, q_class)) || (rc = upload_vec(c->b_q_nseg, q_nseg)) || (rc = upload_vec(c->b_rem_class, rem_class)) ||
         (rc = c->b_cls_begin.ensure((ncls_all + 1) * 4)))
