@@ -124,17 +124,29 @@ def cpu_baseline(packed, metric, min_seconds):
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources and headers the library is built from: PMC records are only quoted for the build they
-    were taken on."""
+    """sha256 of the DEVICE code the library carries (the .hip_fatbin section of libphamclust_hip.so): PMC records are only
+    quoted for the kernels they were taken on.  (Named for what it was in r02's first records: a hash over the kernel
+    sources, which went stale with every comment.)"""
     import hashlib
-    h = hashlib.sha256()
-    base = os.path.join(REPO, "phamclust_amd", "csrc")
-    for name in ("pc_common.h", "pc_api.hip", "pc_nw.hip", "pc_pairs.hip", "pc_plan.hip"):
-        with open(os.path.join(base, name), "rb") as fh:
-            h.update(fh.read())
-    with open(os.path.join(REPO, "include", "phamclust_hip.h"), "rb") as fh:
-        h.update(fh.read())
-    return h.hexdigest()[:16]
+    import struct
+    path = os.path.join(REPO, "phamclust_amd", "csrc", "libphamclust_hip.so")
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    try:
+        shoff, = struct.unpack_from("<Q", blob, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+        def section(i):
+            name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", blob, shoff + i * shentsize)
+            return name, off, size
+        _, stroff, strsize = section(shstrndx)
+        names = blob[stroff:stroff + strsize]
+        for i in range(shnum):
+            name, off, size = section(i)
+            if names[name:names.index(b"\0", name)] == b".hip_fatbin":
+                return hashlib.sha256(blob[off:off + size]).hexdigest()[:16]
+    except (struct.error, ValueError):
+        pass
+    return hashlib.sha256(blob).hexdigest()[:16]
 
 
 def main():

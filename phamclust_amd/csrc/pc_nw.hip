@@ -63,7 +63,7 @@ struct PcCell { int Ho, E, F; uint32_t SH, SE, SF; };
 //   bit 1  E: open == extend:                0: extend (open iff strictly >)  1: open
 //   bit 2  F: open == extend:                0: extend                        1: open
 // DIAG always wins a tie with a gap state.  This C++ cell (general kernel) reads the rule at run time; the
-// systolic kernel's asm cell is instantiated per rule (PC_TIE_* strings below).
+// systolic kernel spells the rule as tags of its 64-bit words (PcTag<RULE> below).
 __device__ __forceinline__ PcCell pc_cell(int Hol, int El, uint32_t SHl, uint32_t SEl, int Hou, int Fu, uint32_t SHu,
                                           uint32_t SFu, int Hod, uint32_t SHd, int sp, bool eq, int rule) {
     PcCell c;
@@ -177,10 +177,6 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 #define PCF_RESET 0x200
 #define PC_MAX_SEG 16
 #define PC_WIN 32                                   // stream entries staged per refill
-
-__device__ __forceinline__ int pc_shr1(int v) {                        // lane k <- lane k-1 (lane 0 keeps 0)
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);  // DPP wave_shr:1
-}
 
 // ---------------------------------------------------------------------------------
 // The DP cell as a LEXICOGRAPHIC MAX on 64-bit words (r02; the r01 cell carried scores and statistics in separate
