@@ -289,17 +289,14 @@ struct PcPick {
     }
 };
 
-// Lanes whose entry is the virtual row -1 (mask m, an SGPR pair written by the step prologue's SDWA compare) forget
-// the previous row: Hou := Fu := -inf (each with the tag its reader expects).
-template <int W, int C, int RULE>
-struct PcReset {
-    static __device__ __forceinline__ void run(double (&Hou)[W], double (&Fu)[W], uint32_t neg_o, uint32_t neg_f, unsigned long long m) {
-        uint32_t h = pc_hi(Hou[C]), f = pc_hi(Fu[C]);
-        asm volatile("v_cndmask_b32 %0, %0, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %4" : "+v"(h), "+v"(f) : "v"(neg_o), "v"(neg_f), "s"(m));
-        Hou[C] = pc_pack(h, pc_lo(Hou[C])); Fu[C] = pc_pack(f, pc_lo(Fu[C]));
-        if constexpr (C + 1 < W) PcReset<W, C + 1, RULE>::run(Hou, Fu, neg_o, neg_f, m);
-    }
-};
+// Alignments of one row stream follow each other without any clearing of the lanes' state: each starts
+// PC_BASE_STEP (in units of the high word: 4 x score) above the one before.  Within an alignment the biased scores
+// span less than 4 x (11 x 4,096 + 65,535 + 4,096 + 2) = 458,756 above and ~200 below the base (lb <= 4,096 columns,
+// la <= 65,535 rows: pc_upload's limit; BLOSUM62's largest entry is 11; bias 1 per anti-diagonal), so 2^20 keeps every
+// value of the previous alignment below every value of the new one, and 1,022 alignments fit between 0x40000000
+// and the first non-finite exponent 0x7ff00000.  A stream holds at most PC_TASK_ROWS / PC_WAVES alignments.
+#define PC_BASE_STEP 0x100000u
+static_assert(PC_TASK_ROWS / PC_WAVES + 1 <= 1000, "alignments per row stream must fit the score headroom");
 
 typedef __attribute__((address_space(3))) const uint32_t pc_lds_u32;
 typedef uint32_t pc_u32x2 __attribute__((ext_vector_type(2)));
@@ -463,9 +460,9 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
     load_prof(a, pw);
     const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out);
     // boundary values the head lanes take (VGPR operands): Ho^(i,-1) = -22, E = -inf, statistics 0; and what a lane starting an alignment resets to
-    const uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0;
-    const uint32_t v_nego = (uint32_t)(PC_NEG4 + TG::tOF), v_negf = (uint32_t)(PC_NEG4 + TG::tF), v_negd = (uint32_t)(PC_NEG4 + TG::tD),
-                   v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
+    const uint32_t v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0, v_base_step = PC_BASE_STEP;
+    // A head lane's boundary values sit on the base of the alignment its stream is in: Ho^(i,-1) = -22 and Ho^(-1,-1) = -12
+    uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
 
     // One row step.  `a`/`pw` are this step's stream entry and profile strip; `a_nxt`/`pw_nxt` receive the next step's.
     auto step = [&](int t, const bool even, uint32_t a, const uint32_t (&pw)[ND], uint32_t& a_nxt, uint32_t (&pw_nxt)[ND]) {
@@ -491,27 +488,32 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
             "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
             "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
             "v_addc_co_u32 %[D0l], %[c2], %[K], %[Hodl], %[c2]\n\t"
+            "s_and_b64 %[lastm], %[lastm], %[om]\n\t"                       // rows ending in the lane that holds column lb-1 (scalar: the compiler would do this AND on the VALU)
+            "s_and_b64 %[rstm], %[rstm], %[hm]\n\t"                         // head lanes whose stream starts an alignment
             : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
               [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
-            : [hm] "s"(headm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+            : [hm] "s"(headm), [om] "s"(outm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
               [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
               [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
-            : "vcc");
+            : "vcc", "scc");
         load_prof(a_nxt, pw_nxt);
         if (even) {                                                       // the head's entries for steps t+2 and t+3
             const uint2 e2 = *(const uint2*)&ring[ring_lane + ((t + 2) & (PC_WIN - 1))];
             e_nxt = e2.x; e_b = e2.y;
         } else e_nxt = e_b;
-        if (rstm != 0) {                                                  // some lane starts an alignment this step (virtual row -1)
-            const unsigned long long hr = rstm & headm;
-            PcReset<W, 0, RULE>::run(Hou, Fu, v_nego, v_negf, rstm);
-            asm volatile("v_cndmask_b32 %0, %0, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %5"        // D := -inf; head: Ho^(-1,-1) = -12
-                         : "+v"(D0_hi), "+v"(HoL_hi) : "v"(v_negd), "v"(v_h00), "s"(rstm), "s"(hr));
+        if (rstm != 0) {                                                  // a stream starts an alignment this step (virtual row -1)
+            // Nothing is cleared.  The new alignment's scores sit PC_BASE_STEP above the previous one's (only the
+            // path statistics leave the kernel, never a score), so whatever the lanes still hold of the previous
+            // alignment -- Hou, Fu, the diagonal term -- loses every max from here on, exactly as -inf would.
+            uint32_t inc;
+            asm volatile("v_cndmask_b32 %0, %4, %5, %6\n\tv_add_u32 %1, %1, %0\n\tv_add_u32 %2, %2, %0\n\tv_cndmask_b32 %3, %3, %2, %6"
+                         : "=&v"(inc), "+v"(v_hb), "+v"(v_h00), "+v"(HoL_hi) : "v"(v_zero), "v"(v_base_step), "s"(rstm));
         }
         const double HoL = pc_pack(HoL_hi, HoL_lo);
         p_HoL = HoL;
         PcRow<W, 0, RULE>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, a, K, o_E);
-        if ((lastm & outm) != 0) {                                        // a row's last cell left the lane holding column lb-1
+        asm volatile("" : "+s"(lastm));                                   // test here, not 140 instructions earlier (the compiler would carry the result as a lane mask: one VALU compare)
+        if (lastm != 0) {                                                 // a row's last cell left the lane holding column lb-1
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
             if ((a & PCF_LAST) && is_out) {
                 const uint32_t st = PcPick<W, 0>::get(Hou, c_out);
