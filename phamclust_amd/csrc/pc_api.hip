@@ -81,6 +81,7 @@ struct pc_ctx {
     bool uploaded = false;
     PcDev dev{};
     std::vector<int32_t> h_gene_len;
+    std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
     int max_gene_len = 0, min_gene_len = 0, max_nph = 0;
     // kernel-variant classes over column genes
     int ncls_all = 0;                       // launch classes: variant * 4 + lanes-per-segment bucket, last = general kernel
@@ -212,7 +213,8 @@ static int pc_class_of(int lb, int variant) {
     if (variant < 0) return nvar * 4;
     const int W = pc_nw_variant_w(variant);
     const int Gs = (lb + W - 1) / W;
-    return variant * 4 + (Gs <= 8 ? 0 : Gs <= 16 ? 1 : Gs <= 32 ? 2 : 3);
+    const int Gb = pc_nw_g_bucket(Gs);
+    return variant * 4 + (Gb == 8 ? 0 : Gb == 16 ? 1 : Gb == 32 ? 2 : 3);
 }
 
 static int apply_shard(pc_ctx* c, int rank, int world) {
@@ -318,12 +320,15 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     if (!codes) { pc_set_error("pc_upload: out of host memory (%zu bytes of residue codes)", codes_size); return PC_ERR_LIMIT; }
     if (code_bytes < 16) memset(codes.get(), PC_PADCODE, 16);
     std::vector<uint64_t> ghash(std::max(G, 1));
+    std::vector<uint8_t> godd(std::max(G, 1), 0);      // gene holds a byte outside the 24-letter alphabet (code >= 24)
     uint8_t lut[256]; build_code_lut(lut);
     parallel_chunks(G, [&](int64_t k0, int64_t k1) {
         for (int64_t k = k0; k < k1; ++k) {
             const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
             const int len = gene_len[k], padded = (len + 15) & ~15;
-            for (int i = 0; i < len; ++i) dst[i] = lut[src[i]];
+            uint8_t top = 0;
+            for (int i = 0; i < len; ++i) { dst[i] = lut[src[i]]; top |= (uint8_t)(dst[i] >= 24); }
+            godd[k] = top;
             for (int i = len; i < padded; ++i) dst[i] = (uint8_t)PC_PADCODE;
             // hash of the padded codes, 8 bytes per multiply (a byte-wise multiply chain cost as much as the encoding itself);
             // equal hash and length are confirmed by comparing the codes, so only its spread matters
@@ -367,7 +372,10 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
             len_cls[len] = pc_class_of(len, variant);
             len_rows[len] = pc_nw_task_rows(len, variant);
         }
-        u_cls[u] = len_cls[len]; ++cls_count[len_cls[len]];
+        // A column sequence with a byte outside the alphabet goes to the general kernel: the systolic variants up to
+        // W = 24 take "identical residues" from a profile row per alphabet letter plus ONE row for every other byte
+        // (pc_nw.hip, PC_INC16_MAX_W), which is exact only while the column holds none of those (as a row, it is fine)
+        u_cls[u] = godd[u_gene[u]] ? ncls_all - 1 : len_cls[len]; ++cls_count[u_cls[u]];
     }
     if (ncls_all > 250) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // class ids travel in a byte, 255 = none
     c->ncls_all = ncls_all;
@@ -380,6 +388,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     std::vector<uint8_t> len_nseg(maxlen + 1, 1), len_rem((size_t)(maxlen + 1) * 16, 255);
     c->cls_max_lb.assign(ncls_all, 0);
     for (int len = 0; len <= maxlen; ++len) if (len_cls[len] >= 0) c->cls_max_lb[len_cls[len]] = std::max(c->cls_max_lb[len_cls[len]], len);
+    for (int u = 0; u < U; ++u) if (u_cls[u] == ncls_all - 1) c->cls_max_lb[ncls_all - 1] = std::max(c->cls_max_lb[ncls_all - 1], (int)gene_len[u_gene[u]]);
     for (int len = 1; len <= maxlen; ++len) {
         const int v = len_var[len];
         if (len_cls[len] < 0 || v < 0) continue;
@@ -410,9 +419,9 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         const int q = (int)cls_pos[u_cls[u]]++;
         const int len = gene_len[u_gene[u]];
         q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];
-        task_rows[q] = len_rows[len];
-        q_class[q] = (uint8_t)u_cls[u]; q_nseg[q] = len_nseg[len];
-        memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16);
+        q_class[q] = (uint8_t)u_cls[u];
+        if (u_cls[u] == ncls_all - 1) { task_rows[q] = pc_nw_task_rows(len, -1); q_nseg[q] = 1; }      // general kernel (rem_class stays 255: no remainder move)
+        else { task_rows[q] = len_rows[len]; q_nseg[q] = len_nseg[len]; memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16); }
     }
     for (int k = 0; k < G; ++k) gene_q[k] = q_of_u[uid[k]];
     int ubits = 1;
@@ -438,7 +447,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
     d.gene_len = c->b_gene_len.as<int32_t>(); d.gene_off = c->b_gene_off.as<int64_t>(); d.codes = c->b_codes.as<uint8_t>();
     d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
-    c->h_gene_len.swap(gene_len);
+    c->h_gene_len.swap(gene_len); c->h_gene_odd.swap(godd);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
     c->max_nph = 0;
     for (int s2 = 0; s2 < N; ++s2) c->max_nph = std::max(c->max_nph, (int)g->nph[s2]);
@@ -813,6 +822,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         const int la = c->h_gene_len[a_gene[k]], lb = c->h_gene_len[b_gene[k]];
         if (la == 0 || lb == 0) { pc_set_error("pc_align_pairs: empty translation at %lld", (long long)k); return PC_ERR_DATA; }
         int v = forced == -2 ? pc_nw_choose_variant(lb) : forced;
+        if (v >= 0 && c->h_gene_odd[b_gene[k]] && !pc_nw_variant_takes_any_byte(v)) v = -1;   // as pc_upload routes such column genes
         if (v >= 0 && lb > 64 * pc_nw_variant_w(v)) { pc_set_error("pc_align_pairs: column gene of %d residues does not fit variant w=%d", lb, pc_nw_variant_w(v)); return PC_ERR_ARG; }
         cls[k] = pc_class_of(lb, v);
         sums[k] = la + lb;

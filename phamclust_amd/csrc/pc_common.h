@@ -111,6 +111,9 @@ int pc_launch_unpack_res(const uint2* res, const int32_t* la_plus_lb, int32_t* n
 int pc_nw_num_variants();
 int pc_nw_variant_w(int v);                       // columns per lane of variant v
 int pc_nw_choose_variant(int lb);                 // -1: general fallback
+int pc_nw_g_bucket(int G);                        // lanes-per-segment bucket bound (8, 16, 32, 64) of a launch class
+int pc_nw_class_waves(int variant, int lb);       // waves per workgroup of the launch class a column gene of lb residues falls in
+int pc_nw_variant_takes_any_byte(int v);          // 0: a column gene with a byte outside the 24-letter alphabet must go to the general kernel
 int pc_nw_task_rows(int lb, int variant);         // rows per workgroup task for that column gene
 int pc_nw_choose_remainder(int lb, int r, int main_variant);   // variant for a bucket's last r < nseg rows, -1: keep them
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,

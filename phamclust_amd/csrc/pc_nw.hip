@@ -228,14 +228,32 @@ __device__ __forceinline__ double pc_retag(double v, uint32_t tag) { return pc_p
 // next cell (+ 3 - tOF, folded into the profile byte) with statistics old Hou's + 0x10000 + (ac == bcn).
 // The first block is asm because of its SDWA forms and because v_cmp's SGPR result must not be read by v_addc sooner than
 // two instructions later (gfx950; nothing pads inside asm): the two independent v_max_f64 sit in between.
-template <int NEXT_BYTE, int RULE>
+template <int NEXT_COL, int RULE, bool INC16>
 __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, double& Hou, double& Fu, double& E, double& Dn,
-                                          uint32_t ac, uint32_t bcn, uint32_t pwn, uint32_t K) {
+                                          uint32_t ac, uint32_t bcn, uint32_t pwn, uint32_t pmn, uint32_t K) {
     using T = PcTag<RULE>;
+    constexpr int NEXT_BYTE = NEXT_COL < 0 ? -1 : (NEXT_COL & 3);
     if constexpr (T::cyclic) HoL = pc_pack(pc_hi(HoL) + (uint32_t)(T::tOE - T::tOF), pc_lo(HoL));
     const uint32_t ohi = pc_hi(Hou), olo = pc_lo(Hou);
     uint32_t dn_hi = 0, dn_lo = 0;
-    unsigned long long c2;
+    if constexpr (NEXT_COL < 0) {
+        asm("v_max_f64 %[E], %[HoL], %[EL]\n\tv_max_f64 %[Fu], %[Hou], %[Fu]" : [E] "=&v"(E), [Fu] "+v"(Fu) : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou));
+    } else if constexpr (INC16) {
+        // the statistics' increment comes from the profile too: a 16-bit entry 0x2000 + (row residue == column residue)
+#define PC_CELL64_B(SEL, WSEL)                                                                                         \
+    asm("v_max_f64 %[E], %[HoL], %[EL]\n\t"                                                                            \
+        "v_max_f64 %[Fu], %[Hou], %[Fu]\n\t"                                                                           \
+        "v_add_u32_sdwa %[dh], %[pwn], %[ohi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
+        "v_add_u32_sdwa %[dl], %[pmn], %[olo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" WSEL " src1_sel:DWORD"    \
+        : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo)                                            \
+        : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn))
+        if constexpr (NEXT_BYTE == 0) PC_CELL64_B("BYTE_0", "WORD_0");
+        else if constexpr (NEXT_BYTE == 1) PC_CELL64_B("BYTE_1", "WORD_1");
+        else if constexpr (NEXT_BYTE == 2) PC_CELL64_B("BYTE_2", "WORD_0");
+        else PC_CELL64_B("BYTE_3", "WORD_1");
+#undef PC_CELL64_B
+    } else {
+        unsigned long long c2;
 #define PC_CELL64_A(SEL)                                                                                               \
     asm("v_cmp_eq_u32_sdwa %[c2], %[ac], %[bcn] src0_sel:BYTE_0 src1_sel:" SEL "\n\t"                                  \
         "v_max_f64 %[E], %[HoL], %[EL]\n\t"                                                                            \
@@ -245,12 +263,12 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
         : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo), [c2] "=&s"(c2)                            \
         : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [ac] "v"(ac), [bcn] "v"(bcn),  \
           [pwn] "v"(pwn), [K] "v"(K))
-    if constexpr (NEXT_BYTE == 0) PC_CELL64_A("BYTE_0");
-    else if constexpr (NEXT_BYTE == 1) PC_CELL64_A("BYTE_1");
-    else if constexpr (NEXT_BYTE == 2) PC_CELL64_A("BYTE_2");
-    else if constexpr (NEXT_BYTE == 3) PC_CELL64_A("BYTE_3");
-    else asm("v_max_f64 %[E], %[HoL], %[EL]\n\tv_max_f64 %[Fu], %[Hou], %[Fu]" : [E] "=&v"(E), [Fu] "+v"(Fu) : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou));
+        if constexpr (NEXT_BYTE == 0) PC_CELL64_A("BYTE_0");
+        else if constexpr (NEXT_BYTE == 1) PC_CELL64_A("BYTE_1");
+        else if constexpr (NEXT_BYTE == 2) PC_CELL64_A("BYTE_2");
+        else PC_CELL64_A("BYTE_3");
 #undef PC_CELL64_A
+    }
     E = pc_retag(E, T::tE);
     Fu = pc_retag(Fu, T::tF);
     double H;
@@ -259,21 +277,49 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
     Dn = pc_pack(dn_hi, dn_lo);
 }
 
-template <int W, int C, int RULE>
+typedef __attribute__((address_space(3))) const uint32_t pc_lds_u32;
+
+// Every variant up to this W exists twice.  INC16: the statistics' increment comes from a second, 16-bit profile, 10
+// instructions per cell, 3 x the LDS; the other compares residues, 11 instructions.  The launcher picks per launch
+// class (pc_nw_class_inc16): the big profile pays while four waves per SIMD still fit beside it.
+#define PC_INC16_MAX_W 24
+#define PC_INC16_K 0x2000u                           // statistics word: n_ident | n_diag << 13 (both <= lb <= 64 * 24)
+
+__host__ __device__ constexpr int pc_prof_rows(bool inc16) { return inc16 ? 25 : 24; }
+__host__ __device__ constexpr int pc_prof_row_dwords(int W, bool inc16) {   // scores (4 per dword), then increments (2 per dword)
+    return (W + 3) / 4 + (inc16 ? (W + 1) / 2 : 0);
+}
+
+template <int W, int C, int RULE, bool INC16>
 struct PcRow {          // compile-time unrolled sweep over the lane's W columns
+    static constexpr int NDM = INC16 ? (W + 1) / 2 : 1;
+    static constexpr int ND = (W + 3) / 4;
+    // `pw` / `pm`: THIS row's score bytes (four columns per register) and 16-bit increments (two per register),
+    // single-buffered: a register is re-loaded from the next row's strip (LDS, at `nxt`: ND score dwords, then the
+    // increments, 64 dwords apart) right after the cell that reads it last
     static __device__ __forceinline__ void run(double D, double HoL, double EL, double (&Hou)[W], double (&Fu)[W],
-                                               const uint32_t (&bc)[(W + 3) / 4], const uint32_t (&pw)[(W + 3) / 4], uint32_t ac, uint32_t K,
-                                               double& E_out) {
+                                               const uint32_t (&bc)[(W + 3) / 4], uint32_t (&pw)[(W + 3) / 4], uint32_t (&pm)[NDM],
+                                               pc_lds_u32* nxt, uint32_t ac, uint32_t K, double& E_out) {
         double E, Dn;
-        constexpr int NB = (C + 1 < W) ? ((C + 1) & 3) : -1;
-        pc_cell64<NB, RULE>(D, HoL, EL, Hou[C], Fu[C], E, Dn, ac, bc[(C + 1 < W) ? ((C + 1) >> 2) : 0], pw[(C + 1 < W) ? ((C + 1) >> 2) : 0], K);
-        if constexpr (C + 1 < W) PcRow<W, C + 1, RULE>::run(Dn, Hou[C], E, Hou, Fu, bc, pw, ac, K, E_out);
+        constexpr int N = (C + 1 < W) ? C + 1 : -1;                      // the column whose diagonal term this cell prepares
+        pc_cell64<N, RULE, INC16>(D, HoL, EL, Hou[C], Fu[C], E, Dn, ac, bc[N < 0 ? 0 : (N >> 2)], pw[N < 0 ? 0 : (N >> 2)], pm[(N < 0 || !INC16) ? 0 : (N >> 1)], K);
+        if constexpr (N >= 0 && (((N & 1) && INC16) || (N & 3) == 3 || N == W - 1)) {
+            __builtin_amdgcn_sched_barrier(0);           // load here, into registers that have just died: hoisted, the loads cost a register each
+            if constexpr ((N & 3) == 3 || N == W - 1) pw[N >> 2] = nxt[(N >> 2) * 64];
+            if constexpr (INC16) pm[N >> 1] = nxt[(ND + (N >> 1)) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (C + 1 < W) PcRow<W, C + 1, RULE, INC16>::run(Dn, Hou[C], E, Hou, Fu, bc, pw, pm, nxt, ac, K, E_out);
         else E_out = E;
     }
 };
 
-#define PC_WAVES 4                                  // waves per workgroup, sharing one profile
-#define PC_WREG (4 * 64 + 2 * PC_MAX_SEG + PC_MAX_SEG * PC_WIN)   // u32 of private LDS per wave
+// Waves per workgroup, sharing one profile: 4, or 8 / 16 where the profile of a long column gene would otherwise leave
+// fewer than four waves per SIMD in the CU's 160 KB of LDS (chosen per launch class by pc_nw_class_waves; the kernel
+// reads it from blockDim).  A variant's ceiling follows from its registers: 16 waves of one workgroup are 4 per SIMD.
+#define PC_MIN_WAVES 4
+__host__ __device__ constexpr int pc_max_waves(int W) { return W <= 19 ? 16 : (W <= 24 ? 8 : 4); }
+__host__ __device__ constexpr int pc_wave_lds_dwords(int nseg) { return 4 * 64 + 2 * PC_MAX_SEG + nseg * PC_WIN; }   // private LDS of a wave with nseg row streams
 
 __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read inside ONE wave (in-order LDS queue)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -294,11 +340,10 @@ struct PcPick {
 // span less than 4 x (11 x 4,096 + 65,535 + 4,096 + 2) = 458,756 above and ~200 below the base (lb <= 4,096 columns,
 // la <= 65,535 rows: pc_upload's limit; BLOSUM62's largest entry is 11; bias 1 per anti-diagonal), so 2^20 keeps every
 // value of the previous alignment below every value of the new one, and 1,022 alignments fit between 0x40000000
-// and the first non-finite exponent 0x7ff00000.  A stream holds at most PC_TASK_ROWS / PC_WAVES alignments.
+// and the first non-finite exponent 0x7ff00000.  A stream holds at most PC_TASK_ROWS / PC_MIN_WAVES alignments.
 #define PC_BASE_STEP 0x100000u
-static_assert(PC_TASK_ROWS / PC_WAVES + 1 <= 1000, "alignments per row stream must fit the score headroom");
+static_assert(PC_TASK_ROWS / PC_MIN_WAVES + 1 <= 1000, "alignments per row stream must fit the score headroom");
 
-typedef __attribute__((address_space(3))) const uint32_t pc_lds_u32;
 typedef uint32_t pc_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t pc_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const pc_u32x2 pc_lds_u32x2;
@@ -306,35 +351,48 @@ typedef __attribute__((address_space(3))) const pc_u32x4 pc_lds_u32x4;
 
 // (second launch bound = waves per SIMD the compiler must leave room for: W = 48 needs 257 registers left to itself, one more
 // than the 256 that let two waves share a SIMD)
-template <int W, int RULE>
-__global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+template <int W, int RULE, bool INC16>
+__global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
                                                                const uint32_t* __restrict__ bucket_dest,
                                                                uint2* __restrict__ res) {
-    constexpr int ND = (W + 3) / 4;                 // profile dwords per lane per residue row
+    constexpr int ND = (W + 3) / 4;                 // score dwords per lane per residue row
+    static_assert(!INC16 || W <= PC_INC16_MAX_W, "INC16 variants");
+    constexpr int NDM = INC16 ? (W + 1) / 2 : 0;    // statistics increments from the profile (PcRow): their dwords per lane per residue row
+    constexpr int RS = pc_prof_row_dwords(W, INC16);   // row stride: scores, then increments
+    constexpr int ROWS = pc_prof_rows(INC16);       // residue rows: 24, + 1 for "any other byte" (scores as '*', identical to nothing)
     // one dynamic LDS array (16-byte aligned): score table | 4 private wave regions | shared profile
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NWV = (int)(blockDim.x >> 6);         // waves of this workgroup
     const int lane = threadIdx.x & 63;
     int8_t (*tab)[24] = (int8_t(*)[24])smem;                         // [24][24]            576 B
-    uint32_t* wreg = smem + 144 + wv * PC_WREG;
+    // The profile, shared by the workgroup's waves: residue row r, strip dword q, lane position k sit at dword
+    // ((r / rpl) * RS + q) * 64 + (r % rpl) * Gb + k, with Gb = the class's lanes-per-segment bound (8..64) and
+    // rpl = 64 / Gb rows per 64-dword line.  A strip dword's q-stride is 256 B, a compile-time immediate of the LDS
+    // reads, and a lane's bank is (r % rpl) * Gb + k whatever it reads: the lanes of one segment never collide, lanes of
+    // different segments only when their rows differ yet agree mod rpl (a lane-major table put all 64 lanes on random banks)
+    // profile bytes: 4 * (S + 12) (the bias note above, scaled to the score field of `hi`) + what turns the stored Ho's tag into DIAG's
+    for (int i = threadIdx.x; i < 576; i += 64 * NWV) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
+
+    const PcTask tk = tasks[blockIdx.x];
+    const int lb = d.gene_len[tk.gene];
+    const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
+    const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
+    const int Gb = G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)), rpl = 64 / Gb;
+    auto row_part = [&](uint32_t r) { return (r / (uint32_t)rpl) * (uint32_t)(RS * 64) + (r % (uint32_t)rpl) * (uint32_t)Gb; };   // dwords
+    const int nseg = min(64 / G, PC_MAX_SEG);
+    const int NS = NWV * nseg;                      // row slots of the workgroup
+    // LDS: score table | the waves' private regions (sized by nseg) | the shared profile
+    uint32_t* wreg = smem + 144 + wv * pc_wave_lds_dwords(nseg);
     uint32_t* row_la = wreg;                                         // [64] this wave's rows: length
     uint32_t* row_pos = row_la + 64;                                 // [64] start of the row's record in its segment's stream
     uint32_t* row_lo = row_pos + 64;                                 // [64] code offset, low / high dword
     uint32_t* row_hi = row_lo + 64;
     uint32_t* seg_len = row_hi + 64;                                 // [16] stream length per segment
     uint32_t* seg_cur = seg_len + PC_MAX_SEG;                        // [16] local row whose record holds the window start
-    uint32_t* ring = seg_cur + PC_MAX_SEG;                           // [16][PC_WIN] staged stream entries
-    uint32_t* prof = smem + 144 + PC_WAVES * PC_WREG;                // [G][24][ND], shared by the 4 waves
-    // profile bytes: 4 * (S + 12) (the bias note above, scaled to the score field of `hi`) + what turns the stored Ho's tag into DIAG's
-    for (int i = threadIdx.x; i < 576; i += 64 * PC_WAVES) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
-
-    const PcTask tk = tasks[blockIdx.x];
-    const int lb = d.gene_len[tk.gene];
-    const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
-    const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
-    const int nseg = min(64 / G, PC_MAX_SEG);
-    const int NS = PC_WAVES * nseg;                 // row slots of the workgroup
+    uint32_t* ring = seg_cur + PC_MAX_SEG;                           // [nseg][PC_WIN] staged stream entries
+    uint32_t* prof = smem + 144 + NWV * pc_wave_lds_dwords(nseg);
     const int seg = lane / G, k = lane - seg * G;
     const bool in_seg = seg < nseg;
     const bool is_head = in_seg && k == 0;
@@ -357,18 +415,32 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
         bc[q] = v;
     }
     __syncthreads();                                 // score table visible
-    if (seg == 0) {                                  // each wave's segment-0 lanes write 6 of the 24 profile rows
+    if (seg == 0) {                                  // each wave's segment-0 lanes write a quarter of the profile rows
 #pragma unroll 1
-        for (int r = wv; r < 24; r += PC_WAVES) {
+        for (int r = wv; r < ROWS; r += NWV) {
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
                 uint32_t v = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = q * 4 + e;
-                    if (c < W) v |= (uint32_t)(uint8_t)tab[r][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
+                    if (c < W) v |= (uint32_t)(uint8_t)tab[min(r, 23)][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
                 }
-                prof[(k * 24 + r) * ND + q] = v;
+                prof[row_part(r) + q * 64 + k] = v;
+            }
+            if constexpr (INC16) {
+                // a column whose residue is "another byte" (code >= 24) never gets here: the host sends such column genes
+                // to the general kernel, because row 24 cannot tell which other byte the row residue is
+#pragma unroll
+                for (int q = 0; q < NDM; ++q) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = q * 2 + e;
+                        if (c < W) v |= (PC_INC16_K + (uint32_t)(r < 24 && (int)((bc[c >> 2] >> (8 * (c & 3))) & 0xffu) == r)) << (16 * e);
+                    }
+                    prof[row_part(r) + (ND + q) * 64 + k] = v;
+                }
             }
         }
     }
@@ -402,8 +474,8 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
     int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
     const int half = lane >> 5, hl = lane & 31;
-    // LDS byte address of my strip table (24 rows of ND dwords)
-    const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + (uint32_t)(in_seg ? k : 0) * (24u * ND * 4u);
+    // LDS byte address of my column of the profile
+    const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + (uint32_t)(in_seg ? k : 0) * 4u;
     const uint32_t ring_lane = (uint32_t)(in_seg ? seg : 0) * PC_WIN;
 
     // Stage PC_WIN stream entries of every segment starting at stream position `base` (two segments per pass).
@@ -422,7 +494,7 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
                     else {
                         const uint8_t* ap = d.codes + (((unsigned long long)row_hi[r] << 32) | row_lo[r]);
                         const uint32_t code = ap[i];
-                        entry = code | (i == (int)row_la[r] - 1 ? PCF_LAST : 0) | ((min(code, 23u) * (ND * 4u)) << 16);
+                        entry = code | (i == (int)row_la[r] - 1 ? PCF_LAST : 0) | (row_part(min(code, (uint32_t)(ROWS - 1))) << 16);
                     }
                     if (hl == PC_WIN - 1) seg_cur[sg] = (uint32_t)r;
                 }
@@ -431,41 +503,36 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
         }
         pc_wave_lds_sync();
     };
-    auto load_prof = [&](uint32_t entry, uint32_t (&dst)[ND]) {     // my strip of the entry's profile row
-        uint32_t addr;                                              // one instruction: the entry's high half + my table
-        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(entry), "v"(prof_lane));
-        if constexpr (ND % 4 == 0) {
-            pc_lds_u32x4* pr = (pc_lds_u32x4*)(size_t)addr;
-#pragma unroll
-            for (int q = 0; q < ND / 4; ++q) { const pc_u32x4 v = pr[q]; dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w; }
-        } else if constexpr (ND % 2 == 0) {
-            pc_lds_u32x2* pr = (pc_lds_u32x2*)(size_t)addr;
-#pragma unroll
-            for (int q = 0; q < ND / 2; ++q) { const pc_u32x2 v = pr[q]; dst[2 * q] = v.x; dst[2 * q + 1] = v.y; }
-        } else {
-            pc_lds_u32* pr = (pc_lds_u32*)(size_t)addr;
-#pragma unroll
-            for (int q = 0; q < ND; ++q) dst[q] = pr[q];
-        }
+    auto row_addr = [&](uint32_t entry) -> uint32_t {               // LDS address of my strip of the entry's profile row
+        return (entry >> 14) + prof_lane;                           // the high half counts dwords; bits 14, 15 (flags) are zero
     };
 
-    // Software pipeline: at step t the row code `a` and its profile strip `pw` are already in registers; the
-    // code of step t+1 (head: ring entry, others: the left neighbour's current code) and its strip are fetched
-    // while the cells of step t execute, and the head's ring entry of step t+2 is read one step ahead of that.
+    // Software pipeline: at step t the row code `a` and its profile strip `pw` (`pm`) are already in registers; the
+    // code of step t+1 (head: ring entry, others: the left neighbour's current code) arrives in the step's prologue and
+    // its strip is fetched register by register while the cells of step t execute (PcRow); the head's ring entry of
+    // step t+2 is read one step ahead of that.
     refill(0);
     uint32_t a = is_head ? ring[ring_lane] : 0u;
     uint32_t e_nxt = ring[ring_lane + 1];                          // head's entry for step 1 (PC_WIN >= 2)
     uint32_t e_b = 0;                                              // entry t+3 (entries t+2, t+3 are fetched as a pair on even steps)
-    uint32_t pw[ND];
-    load_prof(a, pw);
+    uint32_t pw[ND], pm[INC16 ? NDM : 1];                          // this row's score bytes and statistics increments
+    {
+        pc_lds_u32* r0 = (pc_lds_u32*)(size_t)row_addr(a);
+#pragma unroll
+        for (int q = 0; q < ND; ++q) pw[q] = r0[q * 64];
+        if constexpr (INC16) {
+#pragma unroll
+            for (int q = 0; q < NDM; ++q) pm[q] = r0[(ND + q) * 64];
+        } else pm[0] = 0;
+    }
     const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out);
     // boundary values the head lanes take (VGPR operands): Ho^(i,-1) = -22, E = -inf, statistics 0; and what a lane starting an alignment resets to
     const uint32_t v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0, v_base_step = PC_BASE_STEP;
     // A head lane's boundary values sit on the base of the alignment its stream is in: Ho^(i,-1) = -22 and Ho^(-1,-1) = -12
     uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
 
-    // One row step.  `a`/`pw` are this step's stream entry and profile strip; `a_nxt`/`pw_nxt` receive the next step's.
-    auto step = [&](int t, const bool even, uint32_t a, const uint32_t (&pw)[ND], uint32_t& a_nxt, uint32_t (&pw_nxt)[ND]) {
+    // One row step.  `a` is this step's stream entry, `a_nxt` receives the next step's.
+    auto step = [&](int t, const bool even, uint32_t a, uint32_t& a_nxt) {
         if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         // Step prologue, 10 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
         // k-1's value (DPP wave_shr:1 on src0, executed with every lane active), head lanes (vcc) take src1 = their
@@ -474,29 +541,53 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
         // (Ho, E, SH, SE).  The flag tests and the first cell's diagonal term use SDWA byte selects on the raw entry.
         // K.BYTE_2 == 1.
         uint32_t HoL_hi, HoL_lo, EL_hi, EL_lo, D0_hi, D0_lo;
-        unsigned long long rstm, lastm, c2;
-        asm volatile(
-            "s_nop 1\n\t"                                                   // VALU (previous step's cells) -> DPP read: 2 wait states
-            "s_mov_b64 vcc, %[hm]\n\t"
-            "v_cmp_eq_u32_sdwa %[c2], %[a], %[bc0] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-            "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_cndmask_b32_dpp %[Hh], %[Hwh], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // head: E = -inf never wins, its statistics are never read
-            "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-            "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-            "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
-            "v_addc_co_u32 %[D0l], %[c2], %[K], %[Hodl], %[c2]\n\t"
-            "s_and_b64 %[lastm], %[lastm], %[om]\n\t"                       // rows ending in the lane that holds column lb-1 (scalar: the compiler would do this AND on the VALU)
-            "s_and_b64 %[rstm], %[rstm], %[hm]\n\t"                         // head lanes whose stream starts an alignment
-            : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
-              [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
-            : [hm] "s"(headm), [om] "s"(outm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
-              [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
-              [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
-            : "vcc", "scc");
-        load_prof(a_nxt, pw_nxt);
+        unsigned long long rstm, lastm;
+        if constexpr (INC16) {
+            asm volatile(
+                "s_nop 1\n\t"                                               // VALU (previous step's cells) -> DPP read: 2 wait states
+                "s_mov_b64 vcc, %[hm]\n\t"
+                "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Hh], %[Hwh], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // head: E = -inf never wins, its statistics are never read
+                "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                "v_add_u32_sdwa %[D0l], %[pm0], %[Hodl] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                "s_and_b64 %[lastm], %[lastm], %[om]\n\t"                   // rows ending in the lane that holds column lb-1 (scalar: the compiler would do this AND on the VALU)
+                "s_and_b64 %[rstm], %[rstm], %[hm]\n\t"                     // head lanes whose stream starts an alignment
+                : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
+                  [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm)
+                : [hm] "s"(headm), [om] "s"(outm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+                  [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [pw0] "v"(pw[0]), [pm0] "v"(pm[0]),
+                  [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
+                : "vcc", "scc");
+        } else {
+            unsigned long long c2;
+            asm volatile(
+                "s_nop 1\n\t"
+                "s_mov_b64 vcc, %[hm]\n\t"
+                "v_cmp_eq_u32_sdwa %[c2], %[a], %[bc0] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Hh], %[Hwh], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                "v_addc_co_u32 %[D0l], %[c2], %[K], %[Hodl], %[c2]\n\t"
+                "s_and_b64 %[lastm], %[lastm], %[om]\n\t"
+                "s_and_b64 %[rstm], %[rstm], %[hm]\n\t"
+                : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
+                  [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
+                : [hm] "s"(headm), [om] "s"(outm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+                  [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
+                  [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
+                : "vcc", "scc");
+        }
+        pc_lds_u32* nxt = (pc_lds_u32*)(size_t)row_addr(a_nxt);          // the next row's strip
         if (even) {                                                       // the head's entries for steps t+2 and t+3
             const uint2 e2 = *(const uint2*)&ring[ring_lane + ((t + 2) & (PC_WIN - 1))];
             e_nxt = e2.x; e_b = e2.y;
@@ -511,24 +602,25 @@ __global__ __launch_bounds__(64 * PC_WAVES, (W == 48 ? 2 : 1)) void k_nw_systoli
         }
         const double HoL = pc_pack(HoL_hi, HoL_lo);
         p_HoL = HoL;
-        PcRow<W, 0, RULE>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, a, K, o_E);
+        PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
         asm volatile("" : "+s"(lastm));                                   // test here, not 140 instructions earlier (the compiler would carry the result as a lane mask: one VALU compare)
         if (lastm != 0) {                                                 // a row's last cell left the lane holding column lb-1
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
             if ((a & PCF_LAST) && is_out) {
                 const uint32_t st = PcPick<W, 0>::get(Hou, c_out);
-                res[bucket_dest ? bucket_dest[tk.begin + task_row(out_r)] : (uint32_t)(tk.begin + task_row(out_r))] = make_uint2(st & 0xffffu, row_la[out_r] + (uint32_t)lb - (st >> 16));
+                const uint32_t n_ident = INC16 ? (st & (PC_INC16_K - 1)) : (st & 0xffffu), n_diag = INC16 ? (st >> 13) : (st >> 16);
+                res[bucket_dest ? bucket_dest[tk.begin + task_row(out_r)] : (uint32_t)(tk.begin + task_row(out_r))] = make_uint2(n_ident, row_la[out_r] + (uint32_t)lb - n_diag);
                 out_r += nseg;
             }
         }
     };
-    // two steps per iteration with the (code, strip) register sets swapping roles: no copies.  An odd T runs one
+    // two steps per iteration with the two stream-entry registers swapping roles: no copies.  An odd T runs one
     // extra step past the end of every stream (idle entries: no flags, no output).
-    uint32_t a2 = 0; uint32_t pw2[ND];
+    uint32_t a2 = 0;
 #pragma unroll 1
     for (int t = 0; t < T; t += 2) {
-        step(t, true, a, pw, a2, pw2);
-        step(t + 1, false, a2, pw2, a, pw);
+        step(t, true, a, a2);
+        step(t + 1, false, a2, a);
     }
 }
 
@@ -538,6 +630,7 @@ static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 
 int pc_nw_num_variants() { return g_num_variants; }
 int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
+int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants || g_variant_w[v] > PC_INC16_MAX_W; }   // (by W, whichever cell the class would run)
 
 // Variant for a column gene of lb residues.  Time per row step ~ (W + c0 + c1 nseg) cell-equivalents (x 1.014 at
 // W = 22, x 1.022 at W = 24: three waves per SIMD), during which a wave retires nseg rows of lb cells; c1 = 0.535
@@ -595,6 +688,43 @@ int pc_nw_choose_remainder(int lb, int r, int main_variant) {
     return best;
 }
 
+// LDS of one workgroup: score table, the waves' private regions, the profile of a column gene spread over G lanes
+static size_t systolic_lds_bytes(int W, int G, int nw, bool inc16) {
+    const int Gb = pc_nw_g_bucket(G), rpl = 64 / Gb;                      // profile rows per 64-dword line (see the kernel)
+    int nseg_max = Gb == 8 ? PC_MAX_SEG : 64 / (Gb / 2 + 1); if (nseg_max > PC_MAX_SEG) nseg_max = PC_MAX_SEG;   // the bucket's fewest lanes per segment
+    return (size_t)(144 + nw * pc_wave_lds_dwords(nseg_max)) * 4 + (size_t)((pc_prof_rows(inc16) + rpl - 1) / rpl) * pc_prof_row_dwords(W, inc16) * 256;
+}
+// Lanes-per-segment bucket of a launch class (pc_api.hip's classes use the same bounds): every column gene of a launch
+// lies in one bucket, so launch, task sizes and LDS agree on the waves per workgroup without passing it around
+int pc_nw_g_bucket(int G) { return G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)); }
+// Which cell a launch class runs (measured per class with the launches serialised, profiles/r02_l_class_times.txt):
+// the 16-bit increment profile wins 5-7 % where four workgroups still fit a CU beside it (segments of up to 16 lanes)
+// and 3-5 % with 8-wave workgroups on segments of up to 32 lanes for W = 12..19 (W = 20: nothing, W = 24: -7 %); with
+// one segment per wave (up to 64 lanes) the profile of a long gene leaves room for a single 16-wave workgroup per CU
+// and loses 5-10 %.  Elsewhere the residue compare.
+static bool class_inc16(int W, int G) {
+    static const int force = getenv("PC_INC16") ? atoi(getenv("PC_INC16")) : -1;      // tuning: 0 = never, 1 = wherever compiled
+    if (W > PC_INC16_MAX_W) return false;
+    if (force >= 0) return force != 0;
+    const int Gb = pc_nw_g_bucket(G);
+    return Gb <= 16 || (Gb == 32 && W >= 12 && W <= 19);
+}
+// Waves per workgroup: the fewest (4, 8, 16; at most what the variant's registers allow) that put 16 waves on a CU
+// given the LDS the class's largest profile takes; the most allowed if none does
+static int waves_for(int W, int G) {
+    const int Gb = pc_nw_g_bucket(G), top = pc_max_waves(W);
+    const bool inc16 = class_inc16(W, G);
+    if (!inc16) return PC_MIN_WAVES;
+    for (int nw = PC_MIN_WAVES; nw <= top; nw *= 2)
+        if ((int)((size_t)160 * 1024 / systolic_lds_bytes(W, Gb, nw, inc16)) * nw >= 16) return nw;
+    return top;
+}
+int pc_nw_class_waves(int variant, int lb) {
+    if (variant < 0 || variant >= g_num_variants || lb <= 0) return PC_MIN_WAVES;
+    const int W = g_variant_w[variant];
+    return waves_for(W, (lb + W - 1) / W);
+}
+
 // Rows (alignments) per workgroup task for a column gene of lb residues.  A task's 4*nseg row streams each walk
 // rows/(4*nseg) rows of ~lb residues, one residue per step, a step costing ~(W+1) cell slots: a fixed 208 rows makes
 // the tasks of long genes (one segment per wave) run a hundred times longer than those of short ones, and the
@@ -612,17 +742,22 @@ int pc_nw_task_rows(int lb, int variant) {
     int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
     const int64_t steps = task_budget() / (W + 1);
     int64_t per_stream = steps / (lb + 1); if (per_stream < 1) per_stream = 1;
-    const int64_t rows = per_stream * PC_WAVES * nseg;
+    const int64_t rows = per_stream * pc_nw_class_waves(variant, lb) * nseg;
     return (int)(rows > PC_TASK_ROWS ? PC_TASK_ROWS : rows);
 }
 
 template <int W, int RULE>
 static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                                 const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
-    const int ND = (W + 3) / 4;
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
-    const size_t lds = (size_t)(144 + PC_WAVES * PC_WREG) * 4 + (size_t)24 * Gmax * ND * 4;
-    hipLaunchKernelGGL((k_nw_systolic<W, RULE>), dim3((unsigned)ntasks), dim3(64 * PC_WAVES), lds, st, d, tasks, bucket_row, bucket_dest, res);
+    const int nw = waves_for(W, Gmax);
+    bool inc16 = false;
+    if constexpr (W <= PC_INC16_MAX_W) inc16 = class_inc16(W, Gmax);
+    const size_t lds = systolic_lds_bytes(W, Gmax, nw, inc16);
+    if constexpr (W <= PC_INC16_MAX_W) {
+        if (inc16) hipLaunchKernelGGL((k_nw_systolic<W, RULE, true>), dim3((unsigned)ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res);
+        else hipLaunchKernelGGL((k_nw_systolic<W, RULE, false>), dim3((unsigned)ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res);
+    } else hipLaunchKernelGGL((k_nw_systolic<W, RULE, false>), dim3((unsigned)ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d,%d> launch: %s", W, RULE, hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
