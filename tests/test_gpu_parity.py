@@ -7,6 +7,8 @@ alignment outputs (n_ident, n_diag) exactly equal to the oracle's.
 aai / peq fixtures are "oracle_nw" class: parity vs parasail's co-optimal ties is unpinned.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,86 @@ def test_every_systolic_variant(gpu_ctx, native_built, w):
     ident, diag = gpu_ctx.align_pairs(a, b, variant=w)
     _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
     assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
+
+
+_CELL_CHECK = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+from phamclust_amd import hip
+from phamclust_amd.genome import Genome
+from phamclust_amd.pack import pack_genomes
+ctx = hip.Context(0)
+rng = np.random.default_rng(42)
+aa = np.array(list("ACDEFGHIKLMNPQRSTVWYBZX*"))
+bad = 0
+for w in (3, 8, 12, 13, 16, 19, 20, 24):
+    lens = sorted({1, w, 8 * w, 8 * w + 1, 16 * w, 16 * w + 1, 32 * w, 32 * w + 1, min(64 * w, 1200)})
+    g = Genome("cols")
+    for i, ln in enumerate(lens):
+        g.add(f"c{i:02d}", "".join(aa[rng.integers(0, aa.size, ln)]))
+    h = Genome("rows")
+    for i in range(70):
+        base = g.phams[f"c{i % len(lens):02d}"][0]
+        cut = int(rng.integers(0, max(1, len(base))))
+        h.add(f"r{i:02d}", (base[:cut] + "".join(aa[rng.integers(0, aa.size, int(rng.integers(0, 4)))]) + base[cut + int(rng.integers(0, 3)):]) or "M")
+    pk = pack_genomes([g, h])
+    n = len(lens)
+    a = np.repeat(np.arange(n, n + 70, dtype=np.int32), n); b = np.tile(np.arange(n, dtype=np.int32), 70)
+    ctx.upload(pk)
+    ident, diag = ctx.align_pairs(a, b, variant=w)
+    _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+    ok = bool(np.array_equal(ident, wi) and np.array_equal(diag, wd))
+    bad += not ok
+    print("w", w, "ok" if ok else "MISMATCH", flush=True)
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("inc16", ["0", "1"])
+def test_both_cells_everywhere(native_built, inc16):
+    """The systolic variants up to W = 24 exist with two cells (residue compare, 11 instructions; increments from a
+    16-bit profile, 10) and the launcher picks one per launch class.  PC_INC16 forces one of them on EVERY class --
+    segments of 1..64 lanes, so workgroups of 4, 8 and 16 waves -- in a process of its own (the switch is read once)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PC_INC16=inc16)
+    p = subprocess.run([sys.executable, "-c", _CELL_CHECK, root], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.stdout.count(" ok") == 8
+
+
+def test_bytes_outside_the_alphabet(gpu_ctx, native_built):
+    """Residues that are no BLOSUM62 letter (U, O, J, digits ...) score as '*' and are identical only to the same byte
+    (metrics.py:216 counts '|' of a character comparison).  As COLUMN residues they send the gene to the general
+    kernel (the 16-bit increment profile has one row for all of them); as row residues they stay systolic."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(99)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY" * 4 + "UOJ7u"))
+    pool = ["".join(aa[rng.integers(0, aa.size, int(rng.integers(5, 260)))]) for _ in range(12)]
+    pool += ["UUUUUUUU", "AUAUAUAUOJ", "ACDEFGHIKL" * 20]
+    genomes = []
+    for gi in range(9):
+        g = Genome(f"g{gi}")
+        for p in range(6):
+            seq = pool[int(rng.integers(0, len(pool)))]
+            if rng.random() < 0.5:
+                cut = int(rng.integers(0, len(seq)))
+                seq = seq[:cut] + "U" + seq[cut + 1:]
+            g.add(f"pham{p}", seq)
+        genomes.append(g)
+    pk = pack_genomes(genomes)
+    gpu_ctx.upload(pk)
+    for metric in ("aai", "peq"):
+        assert np.array_equal(gpu_ctx.fill(metric, True), O.fill(pk, metric, True)), metric
+    n = pk.n_genes
+    a = rng.integers(0, n, 600).astype(np.int32); b = rng.integers(0, n, 600).astype(np.int32)
+    for variant in (0, 13, 19, 32, -1):
+        ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
+        _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+        assert np.array_equal(ident, wi) and np.array_equal(diag, wd), variant
 
 
 @pytest.mark.parametrize("w", [4, 13])
