@@ -13,10 +13,12 @@ packed genomes already resident in HBM.  With N ranks the SAME matrix is filled 
 Extra objects on that line:
   roofline      the dominant kernels (the K4 alignment launches of one fill, timed with HIP
                 events on the stream they run on, inside the library).  The recurrence is bound
-                by VALU issue: every instruction class of the 11-instruction DP cell (v_max_f64
-                included) retires one wave64 instruction per 4 clocks per SIMD (measured:
-                profiles/valu_issue_rate.json), so peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
-                lane-ops/s and achieved = 11 x DP cells computed / kernel time.  `hbm` inside it
+                by VALU issue: every instruction class of the DP cell (v_max_f64 included) retires
+                one wave64 instruction per 4 clocks per SIMD (measured: profiles/valu_issue_rate.json),
+                so peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz lane-ops/s and achieved = 10 x DP cells
+                computed / kernel time: 10 instructions is the cheaper of the kernel's two cells
+                (launch classes whose LDS cannot hold its 16-bit profile at four waves per SIMD run
+                the 11-instruction cell: counted as a loss, not as a lower ceiling).  `hbm` inside it
                 is the figure the north star asks for: algorithmic bytes = sum(la+lb) residues
                 read + 16 B per alignment (bucket entry in, result out) against 8 TB/s -- small
                 by construction.  `traffic` = HBM bytes of those launches from rocprofv3 PMC
@@ -261,9 +263,11 @@ def main():
         # The bound that binds: VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: a wave64 VALU instruction of every
         # class the DP cell uses (v_max_f64, v_and_or_b32, SDWA forms, v_addc, and a mixed stream of anything) holds its SIMD
         # for 4 clocks at any occupancy (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json; only unmixed runs of plain
-        # add/sub/and/or/xor/mov, f32 add/fma and the 16-bit max/add go at 2), and the cell is 11 of them: four v_max_f64
-        # acting as lexicographic (score, tie-break tag, path statistics) maxima (r01's cell was 15).
-        instr_per_cell = 11
+        # add/sub/and/or/xor/mov, f32 add/fma and the 16-bit max/add go at 2), and the cell is 10 of them: four v_max_f64
+        # acting as lexicographic (score, tie-break tag, path statistics) maxima, two SDWA adds from the profile, four
+        # tag/open-penalty fix-ups (r01's cell was 15; launch classes with long column genes run an 11-instruction
+        # cell that compares residues instead of reading a second profile -- the ceiling is not lowered for them).
+        instr_per_cell = 10
         lane_ops_peak = 256 * 4 * 16 * 2.4e9
         lane_ops = instr_per_cell * gcups * 1e9
         line["roofline"] = {

@@ -314,11 +314,12 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
     }
 };
 
-// Waves per workgroup, sharing one profile: 4, or 8 / 16 where the profile of a long column gene would otherwise leave
+// Waves per workgroup, sharing one profile: 4, or 8 where the profile of a longer column gene would otherwise leave
 // fewer than four waves per SIMD in the CU's 160 KB of LDS (chosen per launch class by pc_nw_class_waves; the kernel
-// reads it from blockDim).  A variant's ceiling follows from its registers: 16 waves of one workgroup are 4 per SIMD.
+// reads it from blockDim).  16-wave workgroups were tried for segments of 64 lanes: one workgroup per CU, 5-10 % slower
+// than the residue-compare cell with its small profile, which those classes run instead.
 #define PC_MIN_WAVES 4
-__host__ __device__ constexpr int pc_max_waves(int W) { return W <= 19 ? 16 : (W <= 24 ? 8 : 4); }
+__host__ __device__ constexpr int pc_max_waves(int W) { return W <= 24 ? 8 : 4; }
 __host__ __device__ constexpr int pc_wave_lds_dwords(int nseg) { return 4 * 64 + 2 * PC_MAX_SEG + nseg * PC_WIN; }   // private LDS of a wave with nseg row streams
 
 __device__ __forceinline__ void pc_wave_lds_sync() {        // LDS write -> read inside ONE wave (in-order LDS queue)
@@ -361,6 +362,10 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     constexpr int NDM = INC16 ? (W + 1) / 2 : 0;    // statistics increments from the profile (PcRow): their dwords per lane per residue row
     constexpr int RS = pc_prof_row_dwords(W, INC16);   // row stride: scores, then increments
     constexpr int ROWS = pc_prof_rows(INC16);       // residue rows: 24, + 1 for "any other byte" (scores as '*', identical to nothing)
+    // A stream entry's high half is its profile row's offset: in bytes where the largest one fits 16 bits (then one SDWA add
+    // makes the row's LDS address), in dwords otherwise (shift + add).  INC16 classes have segments of at most 32 lanes,
+    // i.e. at least 2 rows per 64-dword line
+    constexpr bool BYTE_OFF = ((INC16 ? (ROWS + 1) / 2 : ROWS) * RS * 256) < 65536;
     // one dynamic LDS array (16-byte aligned): score table | 4 private wave regions | shared profile
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
     const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
     const int Gb = G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)), rpl = 64 / Gb;
-    auto row_part = [&](uint32_t r) { return (r / (uint32_t)rpl) * (uint32_t)(RS * 64) + (r % (uint32_t)rpl) * (uint32_t)Gb; };   // dwords
+    auto row_part = [&](uint32_t r) { return ((r / (uint32_t)rpl) * (uint32_t)(RS * 64) + (r % (uint32_t)rpl) * (uint32_t)Gb) * (BYTE_OFF ? 4u : 1u); };   // entry units (dword index where it indexes `prof`: see the build loop)
     const int nseg = min(64 / G, PC_MAX_SEG);
     const int NS = NWV * nseg;                      // row slots of the workgroup
     // LDS: score table | the waves' private regions (sized by nseg) | the shared profile
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
                     const int c = q * 4 + e;
                     if (c < W) v |= (uint32_t)(uint8_t)tab[min(r, 23)][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
                 }
-                prof[row_part(r) + q * 64 + k] = v;
+                prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + q * 64 + k] = v;
             }
             if constexpr (INC16) {
                 // a column whose residue is "another byte" (code >= 24) never gets here: the host sends such column genes
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
                         const int c = q * 2 + e;
                         if (c < W) v |= (PC_INC16_K + (uint32_t)(r < 24 && (int)((bc[c >> 2] >> (8 * (c & 3))) & 0xffu) == r)) << (16 * e);
                     }
-                    prof[row_part(r) + (ND + q) * 64 + k] = v;
+                    prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + (ND + q) * 64 + k] = v;
                 }
             }
         }
@@ -504,7 +509,11 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
         pc_wave_lds_sync();
     };
     auto row_addr = [&](uint32_t entry) -> uint32_t {               // LDS address of my strip of the entry's profile row
-        return (entry >> 14) + prof_lane;                           // the high half counts dwords; bits 14, 15 (flags) are zero
+        if constexpr (BYTE_OFF) {
+            uint32_t addr;                                          // one instruction: the entry's high half + my column
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(entry), "v"(prof_lane));
+            return addr;
+        } else return (entry >> 14) + prof_lane;                    // the high half counts dwords; bits 14, 15 (flags) are zero
     };
 
     // Software pipeline: at step t the row code `a` and its profile strip `pw` (`pm`) are already in registers; the
@@ -705,11 +714,12 @@ int pc_nw_g_bucket(int G) { return G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 
 static bool class_inc16(int W, int G) {
     static const int force = getenv("PC_INC16") ? atoi(getenv("PC_INC16")) : -1;      // tuning: 0 = never, 1 = wherever compiled
     if (W > PC_INC16_MAX_W) return false;
-    if (force >= 0) return force != 0;
     const int Gb = pc_nw_g_bucket(G);
+    if (Gb > 32) return false;                                                        // (the entries' 16-bit row offsets assume >= 2 rows per line)
+    if (force >= 0) return force != 0;
     return Gb <= 16 || (Gb == 32 && W >= 12 && W <= 19);
 }
-// Waves per workgroup: the fewest (4, 8, 16; at most what the variant's registers allow) that put 16 waves on a CU
+// Waves per workgroup: the fewest (4, 8; at most what the variant's registers allow) that put 16 waves on a CU
 // given the LDS the class's largest profile takes; the most allowed if none does
 static int waves_for(int W, int G) {
     const int Gb = pc_nw_g_bucket(G), top = pc_max_waves(W);

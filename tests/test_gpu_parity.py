@@ -144,8 +144,9 @@ sys.exit(1 if bad else 0)
 @pytest.mark.parametrize("inc16", ["0", "1"])
 def test_both_cells_everywhere(native_built, inc16):
     """The systolic variants up to W = 24 exist with two cells (residue compare, 11 instructions; increments from a
-    16-bit profile, 10) and the launcher picks one per launch class.  PC_INC16 forces one of them on EVERY class --
-    segments of 1..64 lanes, so workgroups of 4, 8 and 16 waves -- in a process of its own (the switch is read once)."""
+    16-bit profile, 10) and the launcher picks one per launch class.  PC_INC16 forces one of them on every class that
+    can run it -- segments of 1..32 lanes for the profile cell (workgroups of 4 and 8 waves), all for the compare
+    cell -- in a process of its own (the switch is read once)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PC_INC16=inc16)
