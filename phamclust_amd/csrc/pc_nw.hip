@@ -637,6 +637,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
 static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 32, 48, 64};
 static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 
+static bool class_inc16(int W, int G);
 int pc_nw_num_variants() { return g_num_variants; }
 int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
 int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants || g_variant_w[v] > PC_INC16_MAX_W; }   // (by W, whichever cell the class would run)
@@ -662,7 +663,8 @@ int pc_nw_choose_variant(int lb) {
         const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
         static const double c0 = getenv("PC_CHOOSE_C0") ? atof(getenv("PC_CHOOSE_C0")) : 0.3;
         static const double c1 = getenv("PC_CHOOSE_C1") ? atof(getenv("PC_CHOOSE_C1")) : 0.535;
-        const double cost = (W + c0 + c1 * nseg) * pen / nseg;
+        static const double cell = getenv("PC_CHOOSE_CELL") ? atof(getenv("PC_CHOOSE_CELL")) : 0.94;  // relative cost of the 10-instruction cell's classes (sweep 1.0 / 0.96 / 0.93 / 0.90: 239.6 / 237.8 / 238.1 / 237.9 ms at N=3,000)
+        const double cost = (W + c0 + c1 * nseg) * pen * (class_inc16(W, G) ? cell : 1.0) / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
     return best;
@@ -708,7 +710,8 @@ static size_t systolic_lds_bytes(int W, int G, int nw, bool inc16) {
 int pc_nw_g_bucket(int G) { return G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)); }
 // Which cell a launch class runs (measured per class with the launches serialised, profiles/r02_l_class_times.txt):
 // the 16-bit increment profile wins 5-7 % where four workgroups still fit a CU beside it (segments of up to 16 lanes)
-// and 3-5 % with 8-wave workgroups on segments of up to 32 lanes for W = 12..19 (W = 20: nothing, W = 24: -7 %); with
+// and 3-5 % with 8-wave workgroups on segments of up to 32 lanes for W = 11..19 (W <= 9: -15..-40 %, short strips; W = 20: nothing; W = 24: -6 % in
+// either bucket, its profile needs 8-wave groups even at 16 lanes); with
 // one segment per wave (up to 64 lanes) the profile of a long gene leaves room for a single 16-wave workgroup per CU
 // and loses 5-10 %.  Elsewhere the residue compare.
 static bool class_inc16(int W, int G) {
@@ -717,7 +720,7 @@ static bool class_inc16(int W, int G) {
     const int Gb = pc_nw_g_bucket(G);
     if (Gb > 32) return false;                                                        // (the entries' 16-bit row offsets assume >= 2 rows per line)
     if (force >= 0) return force != 0;
-    return Gb <= 16 || (Gb == 32 && W >= 12 && W <= 19);
+    return (Gb <= 16 && W <= 22) || (Gb == 32 && W >= 11 && W <= 19);
 }
 // Waves per workgroup: the fewest (4, 8; at most what the variant's registers allow) that put 16 waves on a CU
 // given the LDS the class's largest profile takes; the most allowed if none does
