@@ -112,8 +112,8 @@ if valu:
     if line and v.get("SQ_INSTS_VALU"):
         cells = line["roofline"]["dp_cells_computed"]
         out["peq5000_valu_per_fill"]["valu_lane_instructions_per_dp_cell"] = v["SQ_INSTS_VALU"] / vf * 64 / cells
-        out["peq5000_valu_per_fill"]["note"] = ("SQ_INSTS_VALU counts wave-level instructions; x64 lanes / DP cells computed; the hand-scheduled cell is 15, the rest "
-                                               "is idle lanes, step prologues, alignment starts, refills")
+        out["peq5000_valu_per_fill"]["note"] = ("SQ_INSTS_VALU counts wave-level instructions; x64 lanes / DP cells computed; the hand-scheduled cell is 10 or 11 "
+                                               "(per launch class), the rest is idle lanes, step prologues, refills")
 sf, sfc = pmc("pmc_set_fetch")
 sw, swc = pmc("pmc_set_write")
 if sf and sw:
