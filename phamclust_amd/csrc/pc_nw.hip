@@ -152,27 +152,29 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 // the row's residue -- arrives by DPP wave_shr:1 from the neighbour's previous step, so
 // the active cells at any step form an anti-diagonal and neither LDS nor a barrier is
 // involved in the recurrence.  A segment's stream is its row sequences back to back, each
-// preceded by a "virtual row -1" (flag RESET: previous row := -inf, which makes the
-// ordinary recurrence produce the boundary H(-1,j) = -(11+j) with zero stats), so the
-// pipeline fills once per task, not once per alignment.  The stream is staged through LDS
+// preceded by a "virtual row -1" (flag RESET: the ordinary recurrence then produces the
+// boundary H(-1,j) = -(11+j) with zero stats, because the new alignment's scores start a
+// base step above anything the lanes still hold: PC_BASE_STEP below), so the
+// pipeline fills once per task, not once per alignment, and nothing is cleared in between.  The stream is staged through LDS
 // 32 entries at a time (coalesced residue reads); the head lane of a segment only reads
 // one 32-bit entry per step.  The lane holding column lb-1 emits (n_ident, aln_len) when a
 // row flagged LAST leaves it.  Substitution scores come from a per-task profile in LDS:
-// prof[k][r][c] = S(r, b_j)+12 (lane-major: a lane's 24 strips are contiguous, so the strip address is the lane's
-// table base plus the row offset that travels in the stream entry's high half), one ds_read of W bytes per lane per row.
+// score bytes 4*(S(r, b_j)+12) and, for the 10-instruction cell, 16-bit statistics increments, per (residue row r,
+// column j); a row's offset travels in the stream entry's high half, the lane adds its own column, and the strip is
+// read a dword at a time as the cells consume it (layout and bank mapping: at `prof` in the kernel).
 //
 // Scores are kept with an anti-diagonal bias: every stored H, E, F of cell (i,j) carries
 // + (i + j).  Because the extend cost is exactly 1 per step, both extend decrements vanish:
 //   E^(i,j) = max(Ho^(i,j-1), E^(i,j-1)),  F^(i,j) = max(Ho^(i-1,j), F^(i-1,j)),  Ho^ = H^ - 10,
 //   H^(i,j) = max3(Ho^(i-1,j-1) + S + 12, E^, F^); all candidates of one cell share the bias, so every
 // comparison and tie-break is unchanged, and the boundaries become constants (Ho^(i,-1) = Ho^(-1,j) = -22,
-// Ho^(-1,-1) = -12).  The DP cell (pc_cell64) is 11 VALU instructions, column state updated in place, the NEXT
+// Ho^(-1,-1) = -12).  The DP cell (pc_cell64) is 10 or 11 VALU instructions, column state updated in place, the NEXT
 // cell's diagonal term computed from the old column state before it is overwritten (so no register copies), and
 // the one VALU-written SGPR pair read >= 2 instructions later (gfx950 needs 2 wait states there; hipcc pads
 // nothing inside asm).
 // ---------------------------------------------------------------------------------
-// Stream entry (u32): byte 0 residue code | byte 1 flags | high half = byte offset of the code's profile row
-// inside a lane's strip table (so the profile address is one SDWA add, and each flag one SDWA compare).
+// Stream entry (u32): byte 0 residue code | byte 1 flags | high half = offset of the code's profile row
+// (bytes, so that the row's address is one SDWA add; dwords for W >= 48, whose tables pass 64 KB); each flag is one SDWA compare.
 #define PCF_LAST 0x100
 #define PCF_RESET 0x200
 #define PC_MAX_SEG 16
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 //   H = max(D [3], F [tF], E [tE])               DIAG first, then the gap state with the larger tag
 // after each max the result is re-tagged for its next use ((hi & ~3) | tag: one v_and_or_b32), and Ho = H - 10 becomes
 // (hi & ~3) - 40 + tOF.  11 VALU instructions per cell (4 x v_max_f64, 2 x v_and_or, v_and, v_add, and for the next cell's
-// diagonal term v_cmp_eq_sdwa, v_add_sdwa, v_addc), against 15.  Six of the eight tie rules are a consistent order of
+// diagonal term v_cmp_eq_sdwa, v_add_sdwa, v_addc), against r01's 15; 10 where the statistics' increment comes from a
+// second profile (one more v_add_sdwa instead of v_cmp + v_addc: PC_INC16_MAX_W below).  Six of the eight tie rules are a consistent order of
 // (tO, tE, tF); rules 3 and 4 ask for tOE > tE > tF > tOF resp. tOF > tF > tE > tOE, i.e. two different "open" tags, which
 // costs them one more v_add per cell.
 // ---------------------------------------------------------------------------------
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
         } else pm[0] = 0;
     }
     const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out);
-    // boundary values the head lanes take (VGPR operands): Ho^(i,-1) = -22, E = -inf, statistics 0; and what a lane starting an alignment resets to
+    // boundary values the head lanes take (VGPR operands): E = -inf, statistics 0, the base step
     const uint32_t v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0, v_base_step = PC_BASE_STEP;
     // A head lane's boundary values sit on the base of the alignment its stream is in: Ho^(i,-1) = -22 and Ho^(-1,-1) = -12
     uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
