@@ -151,8 +151,8 @@ int pc_assemble_dev(pc_ctx* ctx, const void* gathered_dev, int world, void* out_
  * genomes.  n_ident = comp.count("|"), n_diag = aligned (non-gap) columns, so
  * len(traceback.query) = la + lb - n_diag.  variant: 0 = as pc_fill would choose,
  * -1 = general fallback kernel, w > 0 = force the systolic kernel with w columns per lane
- * (a pair whose COLUMN gene holds a byte outside the 24-letter alphabet still runs on the general
- * kernel when w <= 24, as in pc_fill: those variants keep one profile row for all such bytes).
+ * (a pair whose COLUMN gene holds a byte outside the 24-letter alphabet runs that variant's
+ * residue-compare cell, as in pc_fill: the profile cell keeps one row for all such bytes).
  */
 int pc_align_pairs(pc_ctx* ctx, const int32_t* a_gene, const int32_t* b_gene, int64_t n, int variant,
                    int32_t* n_ident, int32_t* n_diag);

@@ -207,15 +207,20 @@ static void build_code_lut(uint8_t lut[256]) {
     for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)assigned[i];
 }
 
-// launch class of a column gene: variant * 4 + bucket of lanes per segment (<=8, <=16, <=32, <=64)
-static int pc_class_of(int lb, int variant) {
+// Launch class of a column gene: variant * 4 + bucket of lanes per segment (<=8, <=16, <=32, <=64); the same again,
+// nvar * 4 higher, for column genes that hold a byte outside the 24-letter alphabet ("any byte" classes: they must run
+// the residue-compare cell, see pc_common.h); last class: the general kernel.
+static int pc_num_classes() { return pc_nw_num_variants() * 8 + 1; }
+static int pc_class_of(int lb, int variant, bool any_byte) {
     const int nvar = pc_nw_num_variants();
-    if (variant < 0) return nvar * 4;
+    if (variant < 0) return nvar * 8;
     const int W = pc_nw_variant_w(variant);
     const int Gs = (lb + W - 1) / W;
     const int Gb = pc_nw_g_bucket(Gs);
-    return variant * 4 + (Gb == 8 ? 0 : Gb == 16 ? 1 : Gb == 32 ? 2 : 3);
+    return variant * 4 + (Gb == 8 ? 0 : Gb == 16 ? 1 : Gb == 32 ? 2 : 3) + (any_byte && !pc_nw_variant_takes_any_byte(variant) ? nvar * 4 : 0);
 }
+static int pc_class_variant(int cls) { const int nvar = pc_nw_num_variants(); return cls >= nvar * 8 ? -1 : (cls % (nvar * 4)) / 4; }
+static int pc_class_compare_only(int cls) { const int nvar = pc_nw_num_variants(); return cls >= nvar * 4 && cls < nvar * 8; }
 
 static int apply_shard(pc_ctx* c, int rank, int world) {
     const int N = c->dev.N;
@@ -361,7 +366,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     const int U = (int)u_gene.size();
     lap("distinct sequences");
     const int nvar = pc_nw_num_variants();
-    const int ncls_all = nvar * 4 + 1;                 // last class: general kernel
+    const int ncls_all = pc_num_classes();             // last class: general kernel
     std::vector<int> u_cls(U), len_cls(maxlen + 1, -1), len_rows(maxlen + 1, 0), len_var(maxlen + 1, -1);   // per length: class, rows per task, variant
     std::vector<int64_t> cls_count(ncls_all, 0);
     for (int u = 0; u < U; ++u) {
@@ -369,13 +374,13 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         if (len_cls[len] < 0) {
             const int variant = pc_nw_choose_variant(len);
             len_var[len] = variant;
-            len_cls[len] = pc_class_of(len, variant);
-            len_rows[len] = pc_nw_task_rows(len, variant);
+            len_cls[len] = pc_class_of(len, variant, false);
+            len_rows[len] = pc_nw_task_rows(len, variant, 0);
         }
-        // A column sequence with a byte outside the alphabet goes to the general kernel: the systolic variants up to
-        // W = 24 take "identical residues" from a profile row per alphabet letter plus ONE row for every other byte
+        // A column sequence with a byte outside the alphabet goes to its variant's "any byte" class: the profile cell
+        // takes "identical residues" from a profile row per alphabet letter plus ONE row for every other byte
         // (pc_nw.hip, PC_INC16_MAX_W), which is exact only while the column holds none of those (as a row, it is fine)
-        u_cls[u] = godd[u_gene[u]] ? ncls_all - 1 : len_cls[len]; ++cls_count[u_cls[u]];
+        u_cls[u] = godd[u_gene[u]] ? pc_class_of(len, len_var[len], true) : len_cls[len]; ++cls_count[u_cls[u]];
     }
     if (ncls_all > 250) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // class ids travel in a byte, 255 = none
     c->ncls_all = ncls_all;
@@ -388,7 +393,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     std::vector<uint8_t> len_nseg(maxlen + 1, 1), len_rem((size_t)(maxlen + 1) * 16, 255);
     c->cls_max_lb.assign(ncls_all, 0);
     for (int len = 0; len <= maxlen; ++len) if (len_cls[len] >= 0) c->cls_max_lb[len_cls[len]] = std::max(c->cls_max_lb[len_cls[len]], len);
-    for (int u = 0; u < U; ++u) if (u_cls[u] == ncls_all - 1) c->cls_max_lb[ncls_all - 1] = std::max(c->cls_max_lb[ncls_all - 1], (int)gene_len[u_gene[u]]);
+    for (int u = 0; u < U; ++u) if (godd[u_gene[u]]) c->cls_max_lb[u_cls[u]] = std::max(c->cls_max_lb[u_cls[u]], (int)gene_len[u_gene[u]]);
     for (int len = 1; len <= maxlen; ++len) {
         const int v = len_var[len];
         if (len_cls[len] < 0 || v < 0) continue;
@@ -398,7 +403,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         for (int r = 1; r < nseg; ++r) {
             const int vr = pc_nw_choose_remainder(len, r, v);
             if (vr >= 0) {
-                const int cr = pc_class_of(len, vr);
+                const int cr = pc_class_of(len, vr, false);
                 len_rem[(size_t)len * 16 + r] = (uint8_t)cr;
                 c->cls_max_lb[cr] = std::max(c->cls_max_lb[cr], len);
             }
@@ -420,8 +425,18 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         const int len = gene_len[u_gene[u]];
         q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];
         q_class[q] = (uint8_t)u_cls[u];
-        if (u_cls[u] == ncls_all - 1) { task_rows[q] = pc_nw_task_rows(len, -1); q_nseg[q] = 1; }      // general kernel (rem_class stays 255: no remainder move)
-        else { task_rows[q] = len_rows[len]; q_nseg[q] = len_nseg[len]; memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16); }
+        if (u_cls[u] == ncls_all - 1) { task_rows[q] = pc_nw_task_rows(len, -1, 0); q_nseg[q] = 1; }   // general kernel (rem_class stays 255: no remainder move)
+        else if (!godd[u_gene[u]] || u_cls[u] == len_cls[len]) { task_rows[q] = len_rows[len]; q_nseg[q] = len_nseg[len]; memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16); }
+        else {                                                   // "any byte" class: its own task size, remainders to the "any byte" class of their variant
+            task_rows[q] = pc_nw_task_rows(len, len_var[len], 1); q_nseg[q] = len_nseg[len];
+            for (int r = 1; r < 16; ++r) {
+                const uint8_t cr = len_rem[(size_t)len * 16 + r];
+                if (cr == 255) continue;
+                const int ca = pc_class_of(len, pc_class_variant(cr), true);
+                rem_class[(size_t)q * 16 + r] = (uint8_t)ca;
+                c->cls_max_lb[ca] = std::max(c->cls_max_lb[ca], len);
+            }
+        }
     }
     for (int k = 0; k < G; ++k) gene_q[k] = q_of_u[uid[k]];
     int ubits = 1;
@@ -546,7 +561,7 @@ extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? 
 static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[ncls_all+1]*/, const int32_t* cls_max_lb,
                              hipStream_t st, pc_stats* stats, int ppos) {
     const int ncls = c->ncls_all;
-    auto variant_of = [&](int cls) { return cls == ncls - 1 ? -1 : cls / 4; };
+    auto variant_of = [&](int cls) { return pc_class_variant(cls); };
     std::vector<int> order;
     for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
     // longest tasks first (a task's duration grows with its column gene's length): the tail of the fill is then made
@@ -576,7 +591,7 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
                               nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
-                              variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, c->tie_rule, ls);
+                              variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, c->tie_rule, pc_class_compare_only(i), ls);
         if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) % c->n_streams;
@@ -822,9 +837,8 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         const int la = c->h_gene_len[a_gene[k]], lb = c->h_gene_len[b_gene[k]];
         if (la == 0 || lb == 0) { pc_set_error("pc_align_pairs: empty translation at %lld", (long long)k); return PC_ERR_DATA; }
         int v = forced == -2 ? pc_nw_choose_variant(lb) : forced;
-        if (v >= 0 && c->h_gene_odd[b_gene[k]] && !pc_nw_variant_takes_any_byte(v)) v = -1;   // as pc_upload routes such column genes
         if (v >= 0 && lb > 64 * pc_nw_variant_w(v)) { pc_set_error("pc_align_pairs: column gene of %d residues does not fit variant w=%d", lb, pc_nw_variant_w(v)); return PC_ERR_ARG; }
-        cls[k] = pc_class_of(lb, v);
+        cls[k] = pc_class_of(lb, v, c->h_gene_odd[b_gene[k]] != 0);                           // as pc_upload classes such column genes
         sums[k] = la + lb;
     }
     std::vector<int64_t> order(n);
@@ -835,7 +849,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         return x < y;
     });
     std::vector<int32_t> rows(n); std::vector<uint32_t> dest(n); std::vector<PcTask> tasks;
-    const int ncls_all = nvar * 4 + 1;
+    const int ncls_all = pc_num_classes();
     std::vector<uint32_t> cls_task_begin(ncls_all + 1, 0);
     std::vector<int> cls_maxlb(ncls_all, 0);
     {
@@ -845,7 +859,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
             while (cur_cls < cls[k]) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
             int64_t j = i;
             while (j < n && cls[order[j]] == cls[k] && b_gene[order[j]] == b_gene[k]) ++j;
-            const int per = pc_nw_task_rows(c->h_gene_len[b_gene[k]], cls[k] == ncls_all - 1 ? -1 : cls[k] / 4);
+            const int per = pc_nw_task_rows(c->h_gene_len[b_gene[k]], pc_class_variant(cls[k]), pc_class_compare_only(cls[k]));
             for (int64_t r = i; r < j; r += per) {
                 PcTask t; t.gene = b_gene[k]; t.begin = (int32_t)r; t.end = (int32_t)std::min<int64_t>(j, r + per); t.pad = 0;
                 tasks.push_back(t);
@@ -866,14 +880,14 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         const int nt = (int)(cls_task_begin[cl + 1] - cls_task_begin[cl]);
         if (nt <= 0) continue;
         void* scratch = nullptr; size_t sbytes = 0;
-        const int v = cl == ncls_all - 1 ? -1 : cl / 4;
+        const int v = pc_class_variant(cl);
         if (v < 0) {
             sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[cl]);
             if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return rc; }
             scratch = c->b_scratch.p;
         }
         rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[cl], nt, c->b_bucket_row.as<int32_t>(),
-                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], 0, c->tie_rule, st);
+                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], 0, c->tie_rule, pc_class_compare_only(cl), st);
         if (rc != PC_OK) { cleanup(); return rc; }
     }
     (void)hipEventRecord(c->ev[2], st);

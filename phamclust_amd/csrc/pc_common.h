@@ -112,10 +112,12 @@ int pc_nw_num_variants();
 int pc_nw_variant_w(int v);                       // columns per lane of variant v
 int pc_nw_choose_variant(int lb);                 // -1: general fallback
 int pc_nw_g_bucket(int G);                        // lanes-per-segment bucket bound (8, 16, 32, 64) of a launch class
-int pc_nw_class_waves(int variant, int lb);       // waves per workgroup of the launch class a column gene of lb residues falls in
-int pc_nw_variant_takes_any_byte(int v);          // 0: a column gene with a byte outside the 24-letter alphabet must go to the general kernel
-int pc_nw_task_rows(int lb, int variant);         // rows per workgroup task for that column gene
+// compare_only: the launch class is the one for column genes holding a byte outside the 24-letter alphabet, which must run
+// the residue-compare cell (the profile cell keeps ONE row for all such bytes: exact only while the column holds none)
+int pc_nw_class_waves(int variant, int lb, int compare_only);   // waves per workgroup of the launch class a column gene of lb residues falls in
+int pc_nw_variant_takes_any_byte(int v);          // 0: the variant has classes that run the profile cell, so such column genes need the compare_only classes
+int pc_nw_task_rows(int lb, int variant, int compare_only);     // rows per workgroup task for that column gene
 int pc_nw_choose_remainder(int lb, int r, int main_variant);   // variant for a bucket's last r < nseg rows, -1: keep them
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, hipStream_t st);
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, int compare_only, hipStream_t st);
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

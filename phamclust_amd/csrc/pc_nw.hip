@@ -643,7 +643,7 @@ static const int g_num_variants = (int)(sizeof(g_variant_w) / sizeof(int));
 static bool class_inc16(int W, int G);
 int pc_nw_num_variants() { return g_num_variants; }
 int pc_nw_variant_w(int v) { return (v >= 0 && v < g_num_variants) ? g_variant_w[v] : 0; }
-int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants || g_variant_w[v] > PC_INC16_MAX_W; }   // (by W, whichever cell the class would run)
+int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants || g_variant_w[v] > PC_INC16_MAX_W; }   // 0: some class of this variant may run the profile cell
 
 // Variant for a column gene of lb residues.  Time per row step ~ (W + c0 + c1 nseg) cell-equivalents (x 1.014 at
 // W = 22, x 1.022 at W = 24: three waves per SIMD), during which a wave retires nseg rows of lb cells; c1 = 0.535
@@ -727,18 +727,18 @@ static bool class_inc16(int W, int G) {
 }
 // Waves per workgroup: the fewest (4, 8; at most what the variant's registers allow) that put 16 waves on a CU
 // given the LDS the class's largest profile takes; the most allowed if none does
-static int waves_for(int W, int G) {
+static int waves_for(int W, int G, bool compare_only) {
     const int Gb = pc_nw_g_bucket(G), top = pc_max_waves(W);
-    const bool inc16 = class_inc16(W, G);
+    const bool inc16 = !compare_only && class_inc16(W, G);
     if (!inc16) return PC_MIN_WAVES;
     for (int nw = PC_MIN_WAVES; nw <= top; nw *= 2)
         if ((int)((size_t)160 * 1024 / systolic_lds_bytes(W, Gb, nw, inc16)) * nw >= 16) return nw;
     return top;
 }
-int pc_nw_class_waves(int variant, int lb) {
+int pc_nw_class_waves(int variant, int lb, int compare_only) {
     if (variant < 0 || variant >= g_num_variants || lb <= 0) return PC_MIN_WAVES;
     const int W = g_variant_w[variant];
-    return waves_for(W, (lb + W - 1) / W);
+    return waves_for(W, (lb + W - 1) / W, compare_only != 0);
 }
 
 // Rows (alignments) per workgroup task for a column gene of lb residues.  A task's 4*nseg row streams each walk
@@ -751,24 +751,24 @@ static int task_budget() {
     if (!b) { const char* e = getenv("PC_TASK_BUDGET"); b = e ? atoi(e) : 0; if (b <= 0) b = PC_TASK_BUDGET; }
     return b;
 }
-int pc_nw_task_rows(int lb, int variant) {
+int pc_nw_task_rows(int lb, int variant, int compare_only) {
     if (variant < 0 || variant >= g_num_variants || lb <= 0) return 64;       // general kernel: one pass of 64 rows
     const int W = g_variant_w[variant];
     const int G = (lb + W - 1) / W;
     int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
     const int64_t steps = task_budget() / (W + 1);
     int64_t per_stream = steps / (lb + 1); if (per_stream < 1) per_stream = 1;
-    const int64_t rows = per_stream * pc_nw_class_waves(variant, lb) * nseg;
+    const int64_t rows = per_stream * pc_nw_class_waves(variant, lb, compare_only) * nseg;
     return (int)(rows > PC_TASK_ROWS ? PC_TASK_ROWS : rows);
 }
 
 template <int W, int RULE>
 static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                                const uint32_t* bucket_dest, uint2* res, int max_lb, hipStream_t st) {
+                                const uint32_t* bucket_dest, uint2* res, int max_lb, bool compare_only, hipStream_t st) {
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
-    const int nw = waves_for(W, Gmax);
+    const int nw = waves_for(W, Gmax, compare_only);
     bool inc16 = false;
-    if constexpr (W <= PC_INC16_MAX_W) inc16 = class_inc16(W, Gmax);
+    if constexpr (W <= PC_INC16_MAX_W) inc16 = !compare_only && class_inc16(W, Gmax);
     const size_t lds = systolic_lds_bytes(W, Gmax, nw, inc16);
     if constexpr (W <= PC_INC16_MAX_W) {
         if (inc16) hipLaunchKernelGGL((k_nw_systolic<W, RULE, true>), dim3((unsigned)ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res);
@@ -780,16 +780,16 @@ static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks,
 }
 template <int W>
 static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                           const uint32_t* bucket_dest, uint2* res, int max_lb, int rule, hipStream_t st) {
+                           const uint32_t* bucket_dest, uint2* res, int max_lb, bool compare_only, int rule, hipStream_t st) {
     switch (rule) {
-    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
-    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, st);
+    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
     default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
     }
 }
@@ -804,7 +804,7 @@ size_t pc_nw_fallback_scratch_bytes(int max_lb) {
 }
 
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, hipStream_t st) {
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, int compare_only, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
     if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_launch_nw: tie rule %d out of range", rule); return PC_ERR_ARG; }
     if (variant >= 0 && ppos) { pc_set_error("pc_launch_nw: ppos runs on the general kernel only"); return PC_ERR_ARG; }
@@ -813,7 +813,7 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
             pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
         }
         switch (g_variant_w[variant]) {
-#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, rule, st);
+#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only != 0, rule, st);
         PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
         PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24) PC_CASE(32) PC_CASE(48) PC_CASE(64)
 #undef PC_CASE

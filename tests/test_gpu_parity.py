@@ -157,8 +157,9 @@ def test_both_cells_everywhere(native_built, inc16):
 
 def test_bytes_outside_the_alphabet(gpu_ctx, native_built):
     """Residues that are no BLOSUM62 letter (U, O, J, digits ...) score as '*' and are identical only to the same byte
-    (metrics.py:216 counts '|' of a character comparison).  As COLUMN residues they send the gene to the general
-    kernel (the 16-bit increment profile has one row for all of them); as row residues they stay systolic."""
+    (metrics.py:216 counts '|' of a character comparison).  As COLUMN residues they send the gene to its variant's
+    "any byte" launch class, which runs the residue-compare cell (the 16-bit increment profile has one row for all of
+    them); as row residues they change nothing."""
     from phamclust_amd.genome import Genome
     from phamclust_amd.pack import pack_genomes
     O = _oracle()

@@ -38,7 +38,7 @@ for L in map(int, a.lens.split(",")):
     cells = float(np.sum(np.diff(pk.seq_off)[rows].astype(np.float64) * np.diff(pk.seq_off)[cols]))
     out = []
     for w in map(int, a.variants.split(",")):
-        if L > 64 * w:
+        if w > 0 and L > 64 * w:                      # (w = -1: the general kernel, any length)
             out.append("   -   "); continue
         ctx.align_pairs(rows, cols, variant=w)
         ctx.align_pairs(rows, cols, variant=w)
