@@ -11,7 +11,13 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-HIP_SOURCES = ["pc_api.hip", "pc_pairs.hip", "pc_plan.hip", "pc_nw.hip"]
+# (source, object, extra flags): the systolic alignment kernel's tie rules are spread over four translation units
+HIP_UNITS = [("pc_api.hip", "pc_api.o", []), ("pc_pairs.hip", "pc_pairs.o", []), ("pc_plan.hip", "pc_plan.o", []),
+             ("pc_nw.hip", "pc_nw.o", []),
+             ("pc_nw_rules.hip", "pc_nw_r23.o", ["-DPC_RULE_A=2", "-DPC_RULE_B=3"]),
+             ("pc_nw_rules.hip", "pc_nw_r45.o", ["-DPC_RULE_A=4", "-DPC_RULE_B=5"]),
+             ("pc_nw_rules.hip", "pc_nw_r67.o", ["-DPC_RULE_A=6", "-DPC_RULE_B=7"])]
+HIP_SOURCES = sorted({u[0] for u in HIP_UNITS})
 HIP_LIB = os.path.join(CSRC, "libphamclust_hip.so")
 SYNTH_LIB = os.path.join(CSRC, "libpc_synth.so")
 PACK_LIB = os.path.join(CSRC, "libpc_pack.so")
@@ -27,18 +33,18 @@ def _stale(target, sources):
 
 def build_hip(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "pc_common.h"),
+    headers = [os.path.join(CSRC, "pc_common.h"), os.path.join(CSRC, "pc_nw_systolic.h"),
                os.path.join(CSRC, "..", "..", "include", "phamclust_hip.h")]
     objs, jobs = [], []
-    for src in HIP_SOURCES:
+    for src, obj_name, extra in HIP_UNITS:
         src_path = os.path.join(CSRC, src)
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, obj_name)
         if force or _stale(obj, [src_path] + headers):
-            cmd = [hipcc] + HIPCC_FLAGS + ["-c", src_path, "-o", obj]
+            cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", src_path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))          # the translation units compile side by side
-        objs.append(obj)                                       # (pc_nw.hip: 24 widths x 8 tie rules, ~70 s)
+        objs.append(obj)                                       # (the systolic kernel: 8 tie rules x 45 kernels, ~40 s per unit)
     failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])

@@ -365,7 +365,6 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     }
     const int U = (int)u_gene.size();
     lap("distinct sequences");
-    const int nvar = pc_nw_num_variants();
     const int ncls_all = pc_num_classes();             // last class: general kernel
     std::vector<int> u_cls(U), len_cls(maxlen + 1, -1), len_rows(maxlen + 1, 0), len_var(maxlen + 1, -1);   // per length: class, rows per task, variant
     std::vector<int64_t> cls_count(ncls_all, 0);

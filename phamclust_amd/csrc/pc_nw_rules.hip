@@ -1,0 +1,11 @@
+// pc_nw_rules.hip -- explicit instantiations of the systolic kernel for two tie rules (PC_RULE_A, PC_RULE_B; default 2, 3).
+// build.py compiles this file three times (-DPC_RULE_A=2 -DPC_RULE_B=3, 4/5, 6/7) next to pc_nw.hip, which holds rules 0, 1.
+#include "pc_nw_systolic.h"
+#ifndef PC_RULE_A
+#define PC_RULE_A 2
+#define PC_RULE_B 3
+#endif
+#define PC_INST1(W) template int pc_systolic_launch<W, PC_RULE_A, false> PC_SYSTOLIC_SIG; template int pc_systolic_launch<W, PC_RULE_B, false> PC_SYSTOLIC_SIG;
+#define PC_INST2(W) PC_INST1(W) template int pc_systolic_launch<W, PC_RULE_A, true> PC_SYSTOLIC_SIG; template int pc_systolic_launch<W, PC_RULE_B, true> PC_SYSTOLIC_SIG;
+PC_FOR_W2(PC_INST2)
+PC_FOR_W1(PC_INST1)
