@@ -79,7 +79,9 @@ static __constant__ int8_t c_b62[24][24] = {
 #define PCF_LAST 0x100
 #define PCF_RESET 0x200
 #define PC_MAX_SEG 16
-#define PC_WIN 32                                   // stream entries staged per refill
+#ifndef PC_WIN
+#define PC_WIN 32                                   // stream entries staged per refill (32 or 64: one or two segments per 64-lane pass)
+#endif
 
 // ---------------------------------------------------------------------------------
 // The DP cell as a LEXICOGRAPHIC MAX on 64-bit words (r02; the r01 cell carried scores and statistics in separate
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
     const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
     const int Gb = G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)), rpl = 64 / Gb;
-    auto row_part = [&](uint32_t r) { return ((r / (uint32_t)rpl) * (uint32_t)(RS * 64) + (r % (uint32_t)rpl) * (uint32_t)Gb) * (BYTE_OFF ? 4u : 1u); };   // entry units (dword index where it indexes `prof`: see the build loop)
+    const int rpl_sh = 6 - (Gb == 8 ? 3 : (Gb == 16 ? 4 : (Gb == 32 ? 5 : 6)));       // log2(rpl): no division in row_part
+    auto row_part = [&](uint32_t r) { return ((r >> rpl_sh) * (uint32_t)(RS * 64) + (r & (uint32_t)(rpl - 1)) * (uint32_t)Gb) * (BYTE_OFF ? 4u : 1u); };   // entry units (dword index where it indexes `prof`: see the build loop)
     const int nseg = min(64 / G, PC_MAX_SEG);
     const int NS = NWV * nseg;                      // row slots of the workgroup
     // LDS: score table | the waves' private regions (sized by nseg) | the shared profile
@@ -382,15 +385,15 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     double p_HoL = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u);     // what I received last step (diagonal of column 0)
     int out_r = seg;                                 // out lane: local row of the next result
     const uint32_t K = 0x10000u;
-    const int half = lane >> 5, hl = lane & 31;
+    const int half = lane / PC_WIN, hl = lane % PC_WIN;               // refill: which of the pass's segments, which entry
     // LDS byte address of my column of the profile
     const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + (uint32_t)(in_seg ? k : 0) * 4u;
     const uint32_t ring_lane = (uint32_t)(in_seg ? seg : 0) * PC_WIN;
 
-    // Stage PC_WIN stream entries of every segment starting at stream position `base` (two segments per pass).
+    // Stage PC_WIN stream entries of every segment starting at stream position `base` (64 / PC_WIN segments per pass).
     auto refill = [&](int base) {
         pc_wave_lds_sync();
-        for (int s0 = 0; s0 < nseg; s0 += 2) {
+        for (int s0 = 0; s0 < nseg; s0 += 64 / PC_WIN) {
             const int sg = s0 + half;
             uint32_t entry = 0;
             if (sg < nseg) {
