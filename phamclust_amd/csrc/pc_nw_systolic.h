@@ -383,7 +383,8 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     for (int c = 0; c < W; ++c) { Hou[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u); Fu[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tF), 0u); }
     double o_E = pc_pack((uint32_t)(PC_NEG4 + TG::tE), 0u);        // my last column's E of the previous step
     double p_HoL = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u);     // what I received last step (diagonal of column 0)
-    int out_r = seg;                                 // out lane: local row of the next result
+    int out_r = seg;                                 // out lane: local row of the next result ...
+    int out_tr = wv * nseg + seg;                    // ... and its row of the task (= task_row(out_r), kept without the division)
     const uint32_t K = 0x10000u;
     const int half = lane / PC_WIN, hl = lane % PC_WIN;               // refill: which of the pass's segments, which entry
     // LDS byte address of my column of the profile
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
             for (int q = 0; q < NDM; ++q) pm[q] = r0[(ND + q) * 64];
         } else pm[0] = 0;
     }
-    const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out);
+    const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out), headoutm = headm | outm;
     // boundary values the head lanes take (VGPR operands): E = -inf, statistics 0, the base step
     const uint32_t v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0, v_base_step = PC_BASE_STEP;
     // A head lane's boundary values sit on the base of the alignment its stream is in: Ho^(i,-1) = -22 and Ho^(-1,-1) = -12
@@ -450,14 +451,14 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     // One row step.  `a` is this step's stream entry, `a_nxt` receives the next step's.
     auto step = [&](int t, const bool even, uint32_t a, uint32_t& a_nxt) {
         if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
-        // Step prologue, 10 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
+        // Step prologue, 9 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
         // k-1's value (DPP wave_shr:1 on src0, executed with every lane active), head lanes (vcc) take src1 = their
         // boundary value instead: the next entry from the ring, Ho^(i,-1) = -22, E = -inf, stats 0.  Ho and E are 64-bit
         // words now, so the four value exchanges are their two halves each -- the same count as the r01 kernel's
         // (Ho, E, SH, SE).  The flag tests and the first cell's diagonal term use SDWA byte selects on the raw entry.
         // K.BYTE_2 == 1.
         uint32_t HoL_hi, HoL_lo, EL_hi, EL_lo, D0_hi, D0_lo;
-        unsigned long long rstm, lastm;
+        unsigned long long anym;
         if constexpr (INC16) {
             asm volatile(
                 "s_nop 1\n\t"                                               // VALU (previous step's cells) -> DPP read: 2 wait states
@@ -467,15 +468,13 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
                 "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // head: E = -inf never wins, its statistics are never read
-                "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-                "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                "v_cmp_ne_u32_sdwa %[anym], %[a], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"                    // any flag (LAST, RESET) on my entry
                 "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
                 "v_add_u32_sdwa %[D0l], %[pm0], %[Hodl] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
-                "s_and_b64 %[lastm], %[lastm], %[om]\n\t"                   // rows ending in the lane that holds column lb-1 (scalar: the compiler would do this AND on the VALU)
-                "s_and_b64 %[rstm], %[rstm], %[hm]\n\t"                     // head lanes whose stream starts an alignment
+                "s_and_b64 %[anym], %[anym], %[hom]\n\t"                    // ... in a head lane or in the lane that holds column lb-1 (scalar: the compiler would do this AND on the VALU)
                 : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
-                  [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm)
-                : [hm] "s"(headm), [om] "s"(outm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+                  [D0l] "=&v"(D0_lo), [anym] "=&s"(anym)
+                : [hm] "s"(headm), [hom] "s"(headoutm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
                   [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [pw0] "v"(pw[0]), [pm0] "v"(pm[0]),
                   [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
                 : "vcc", "scc");
@@ -490,15 +489,13 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
                 "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cmp_lt_u32_sdwa %[rstm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-                "v_cmp_eq_u32_sdwa %[lastm], %[K], %[a] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                "v_cmp_ne_u32_sdwa %[anym], %[a], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"                    // any flag (LAST, RESET) on my entry
                 "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
                 "v_addc_co_u32 %[D0l], %[c2], %[K], %[Hodl], %[c2]\n\t"
-                "s_and_b64 %[lastm], %[lastm], %[om]\n\t"
-                "s_and_b64 %[rstm], %[rstm], %[hm]\n\t"
+                "s_and_b64 %[anym], %[anym], %[hom]\n\t"
                 : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
-                  [D0l] "=&v"(D0_lo), [rstm] "=&s"(rstm), [lastm] "=&s"(lastm), [c2] "=&s"(c2)
-                : [hm] "s"(headm), [om] "s"(outm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+                  [D0l] "=&v"(D0_lo), [anym] "=&s"(anym), [c2] "=&s"(c2)
+                : [hm] "s"(headm), [hom] "s"(headoutm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
                   [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
                   [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
                 : "vcc", "scc");
@@ -508,6 +505,15 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
             const uint2 e2 = *(const uint2*)&ring[ring_lane + ((t + 2) & (PC_WIN - 1))];
             e_nxt = e2.x; e_b = e2.y;
         } else e_nxt = e_b;
+        // Flags are rare (two entries per row, and only a head lane or the output lane acts on them): one compare per step,
+        // the two that tell them apart only when it fires
+        unsigned long long rstm = 0, lastm = 0;
+        if (anym != 0)
+            asm volatile("v_cmp_lt_u32_sdwa %0, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"       // RESET: flag byte > 1 (K.BYTE_2 == 1)
+                         "v_cmp_eq_u32_sdwa %1, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"       // LAST:  flag byte == 1
+                         "s_and_b64 %0, %0, %4\n\t"                                              // head lanes whose stream starts an alignment
+                         "s_and_b64 %1, %1, %5"                                                  // rows ending in the lane that holds column lb-1
+                         : "=&s"(rstm), "=&s"(lastm) : "v"(K), "v"(a), "s"(headm), "s"(outm) : "scc");
         if (rstm != 0) {                                                  // a stream starts an alignment this step (virtual row -1)
             // Nothing is cleared.  The new alignment's scores sit PC_BASE_STEP above the previous one's (only the
             // path statistics leave the kernel, never a score), so whatever the lanes still hold of the previous
@@ -525,8 +531,8 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
             if ((a & PCF_LAST) && is_out) {
                 const uint32_t st = PcPick<W, 0>::get(Hou, c_out);
                 const uint32_t n_ident = INC16 ? (st & (PC_INC16_K - 1)) : (st & 0xffffu), n_diag = INC16 ? (st >> 13) : (st >> 16);
-                res[bucket_dest ? bucket_dest[tk.begin + task_row(out_r)] : (uint32_t)(tk.begin + task_row(out_r))] = make_uint2(n_ident, row_la[out_r] + (uint32_t)lb - n_diag);
-                out_r += nseg;
+                res[bucket_dest ? bucket_dest[tk.begin + out_tr] : (uint32_t)(tk.begin + out_tr)] = make_uint2(n_ident, row_la[out_r] + (uint32_t)lb - n_diag);
+                out_r += nseg; out_tr += NS;
             }
         }
     };
