@@ -577,7 +577,9 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     // scratch of the general kernel: sized once for the longest column gene that will use it (never re-allocated
     // between launches)
     size_t sbytes = 0;
-    for (int i : order) if (ppos || variant_of(i) < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(cls_max_lb[i]));
+    // percent-positives: systolic where the profile cell can run (it reads "positive" from a table), general kernel elsewhere
+    auto launch_variant = [&](int i) { const int v = variant_of(i); return (ppos && !pc_nw_ppos_systolic(v, cls_max_lb[i])) ? pc_nw_ppos_variant(cls_max_lb[i]) : v; };
+    for (int i : order) if (launch_variant(i) < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(cls_max_lb[i]));
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     constexpr int kAux = pc_ctx::kAux;
     PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
@@ -585,7 +587,7 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     int slot = 0, first_error = PC_OK;
     for (int i : order) {
         const int nt = (int)(task_begin[i + 1] - task_begin[i]);
-        const int variant = ppos ? -1 : variant_of(i);            // percent-positives: general kernel (rare, no CLI route)
+        const int variant = launch_variant(i);
         // launches that use the one scratch slab stay in order on the caller's stream
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),

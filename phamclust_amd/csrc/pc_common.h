@@ -117,6 +117,8 @@ int pc_nw_g_bucket(int G);                        // lanes-per-segment bucket bo
 int pc_nw_class_waves(int variant, int lb, int compare_only);   // waves per workgroup of the launch class a column gene of lb residues falls in
 int pc_nw_variant_takes_any_byte(int v);          // 0: the variant has classes that run the profile cell, so such column genes need the compare_only classes
 int pc_nw_task_rows(int lb, int variant, int compare_only);     // rows per workgroup task for that column gene
+int pc_nw_ppos_systolic(int variant, int max_lb); // 1: a percent-positives launch of this class can run on the systolic kernel (its profile cell)
+int pc_nw_ppos_variant(int max_lb);               // the variant to run it on when the class's own cannot; -1: general kernel
 int pc_nw_choose_remainder(int lb, int r, int main_variant);   // variant for a bucket's last r < nseg rows, -1: keep them
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, int compare_only, hipStream_t st);

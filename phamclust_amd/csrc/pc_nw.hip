@@ -180,10 +180,12 @@ int pc_nw_choose_remainder(int lb, int r, int main_variant) {
 }
 
 // LDS of one workgroup: score table, the waves' private regions, the profile of a column gene spread over G lanes
-static size_t systolic_lds_bytes(int W, int G, int nw, bool inc16) {
+static size_t systolic_lds_bytes(int W, int G, int nw, bool inc16, bool any_bucket = false) {
     const int Gb = pc_nw_g_bucket(G), rpl = 64 / Gb;                      // profile rows per 64-dword line (see the kernel)
-    int nseg_max = Gb == 8 ? PC_MAX_SEG : 64 / (Gb / 2 + 1); if (nseg_max > PC_MAX_SEG) nseg_max = PC_MAX_SEG;   // the bucket's fewest lanes per segment
-    return (size_t)(144 + nw * pc_wave_lds_dwords(nseg_max)) * 4 + (size_t)((pc_prof_rows(inc16) + rpl - 1) / rpl) * pc_prof_row_dwords(W, inc16) * 256;
+    int nseg_max = (Gb == 8 || any_bucket) ? PC_MAX_SEG : 64 / (Gb / 2 + 1); if (nseg_max > PC_MAX_SEG) nseg_max = PC_MAX_SEG;   // the bucket's fewest lanes per segment (any_bucket: the launch's column genes may be shorter than its bucket)
+    const size_t lines = (inc16 && Gb == 64) ? (size_t)2 * ((pc_prof_rows(inc16) + 1) / 2)       // two half tables of 2 rows per line
+                                             : (size_t)((pc_prof_rows(inc16) + rpl - 1) / rpl);
+    return (size_t)(144 + nw * pc_wave_lds_dwords(nseg_max)) * 4 + lines * pc_prof_row_dwords(W, inc16) * 256;
 }
 // Lanes-per-segment bucket of a launch class (pc_api.hip's classes use the same bounds): every column gene of a launch
 // lies in one bucket, so launch, task sizes and LDS agree on the waves per workgroup without passing it around
@@ -198,15 +200,20 @@ static bool class_inc16(int W, int G) {
     static const int force = getenv("PC_INC16") ? atoi(getenv("PC_INC16")) : -1;      // tuning: 0 = never, 1 = wherever compiled
     if (W > PC_INC16_MAX_W) return false;
     const int Gb = pc_nw_g_bucket(G);
-    if (Gb > 32) return false;                                                        // (the entries' 16-bit row offsets assume >= 2 rows per line)
+    if (Gb > 32) return false;                                                        // (measured: no room for enough waves; only percent-positives launches run the profile cell there)
     if (force >= 0) return force != 0;
     return (Gb <= 16 && W <= 22) || (Gb == 32 && W >= 11 && W <= 19);
 }
 // Waves per workgroup: the fewest (4, 8; at most what the variant's registers allow) that put 16 waves on a CU
 // given the LDS the class's largest profile takes; the most allowed if none does
-static int waves_for(int W, int G, bool compare_only) {
+// cell_mode: 0 = the class's own choice, 1 = compare cell ("any byte" classes), 2 = profile cell (percent-positives runs)
+static bool mode_inc16(int W, int G, int cell_mode) {
+    if (cell_mode == 2) return W <= PC_INC16_MAX_W && G <= 64;
+    return cell_mode == 0 && class_inc16(W, G);
+}
+static int waves_for(int W, int G, int cell_mode) {
     const int Gb = pc_nw_g_bucket(G), top = pc_max_waves(W);
-    const bool inc16 = !compare_only && class_inc16(W, G);
+    const bool inc16 = mode_inc16(W, G, cell_mode);
     if (!inc16) return PC_MIN_WAVES;
     for (int nw = PC_MIN_WAVES; nw <= top; nw *= 2)
         if ((int)((size_t)160 * 1024 / systolic_lds_bytes(W, Gb, nw, inc16)) * nw >= 16) return nw;
@@ -215,7 +222,21 @@ static int waves_for(int W, int G, bool compare_only) {
 int pc_nw_class_waves(int variant, int lb, int compare_only) {
     if (variant < 0 || variant >= g_num_variants || lb <= 0) return PC_MIN_WAVES;
     const int W = g_variant_w[variant];
-    return waves_for(W, (lb + W - 1) / W, compare_only != 0);
+    return waves_for(W, (lb + W - 1) / W, compare_only != 0 ? 1 : 0);
+}
+// Percent-positives (aai with ppos=True) needs the profile cell -- "positive" is a property of (row residue, column residue),
+// i.e. a table entry, not a residue compare: systolic where that cell can run, the general kernel elsewhere
+int pc_nw_ppos_systolic(int variant, int max_lb) {
+    if (variant < 0 || variant >= g_num_variants || max_lb <= 0) return 0;
+    const int W = g_variant_w[variant];
+    return mode_inc16(W, (max_lb + W - 1) / W, 2) ? 1 : 0;
+}
+// ... and for a class whose own variant cannot (the wide ones, W >= 32, have no profile cell): the widest variant that has
+// one, if it can take the class's longest column gene (tasks do not depend on the variant that runs them); -1: none,
+// i.e. column genes over 64 x 24 = 1,536 residues stay on the general kernel
+int pc_nw_ppos_variant(int max_lb) {
+    for (int v = g_num_variants - 1; v >= 0; --v) if (pc_nw_ppos_systolic(v, max_lb)) return v;
+    return -1;
 }
 
 // Rows (alignments) per workgroup task for a column gene of lb residues.  A task's 4*nseg row streams each walk
@@ -241,32 +262,34 @@ int pc_nw_task_rows(int lb, int variant, int compare_only) {
 
 template <int W, int RULE>
 static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                                const uint32_t* bucket_dest, uint2* res, int max_lb, bool compare_only, hipStream_t st) {
+                                const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, hipStream_t st) {
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
-    const int nw = waves_for(W, Gmax, compare_only);
+    const int nw = waves_for(W, Gmax, cell_mode);
     bool inc16 = false;
-    if constexpr (W <= PC_INC16_MAX_W) inc16 = !compare_only && class_inc16(W, Gmax);
-    const size_t lds = systolic_lds_bytes(W, Gmax, nw, inc16);
+    if constexpr (W <= PC_INC16_MAX_W) inc16 = mode_inc16(W, Gmax, cell_mode);
+    const int ppos = cell_mode == 2;
+    if (ppos && !inc16) { pc_set_error("k_nw_systolic<%d>: percent-positives needs the profile cell (W <= %d)", W, PC_INC16_MAX_W); return PC_ERR_ARG; }
+    const size_t lds = systolic_lds_bytes(W, Gmax, nw, inc16, cell_mode == 2);
     hipError_t e;
     if constexpr (W <= PC_INC16_MAX_W) {
-        if (inc16) e = (hipError_t)pc_systolic_launch<W, RULE, true>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res);
-        else e = (hipError_t)pc_systolic_launch<W, RULE, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res);
-    } else e = (hipError_t)pc_systolic_launch<W, RULE, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res);
+        if (inc16) e = (hipError_t)pc_systolic_launch<W, RULE, true>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, ppos);
+        else e = (hipError_t)pc_systolic_launch<W, RULE, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, 0);
+    } else e = (hipError_t)pc_systolic_launch<W, RULE, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, 0);
     if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d,%d> launch: %s", W, RULE, hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
 }
 template <int W>
 static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                           const uint32_t* bucket_dest, uint2* res, int max_lb, bool compare_only, int rule, hipStream_t st) {
+                           const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, int rule, hipStream_t st) {
     switch (rule) {
-    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
-    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only, st);
+    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
     default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
     }
 }
@@ -284,13 +307,13 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, int compare_only, hipStream_t st) {
     if (ntasks <= 0) return PC_OK;
     if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_launch_nw: tie rule %d out of range", rule); return PC_ERR_ARG; }
-    if (variant >= 0 && ppos) { pc_set_error("pc_launch_nw: ppos runs on the general kernel only"); return PC_ERR_ARG; }
+    if (variant >= 0 && ppos && !pc_nw_ppos_systolic(variant, max_lb)) { pc_set_error("pc_launch_nw: percent-positives cannot run on variant %d for %d columns", variant, max_lb); return PC_ERR_ARG; }
     if (variant >= 0) {
         if (variant >= g_num_variants || max_lb > 64 * g_variant_w[variant]) {
             pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
         }
         switch (g_variant_w[variant]) {
-#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, compare_only != 0, rule, st);
+#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, ppos ? 2 : (compare_only != 0 ? 1 : 0), rule, st);
         PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
         PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24) PC_CASE(32) PC_CASE(48) PC_CASE(64)
 #undef PC_CASE

@@ -262,16 +262,19 @@ template <int W, int RULE, bool INC16>
 __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
                                                                const int32_t* __restrict__ bucket_row,
                                                                const uint32_t* __restrict__ bucket_dest,
-                                                               uint2* __restrict__ res) {
+                                                               uint2* __restrict__ res, int ppos) {
     constexpr int ND = (W + 3) / 4;                 // score dwords per lane per residue row
     static_assert(!INC16 || W <= PC_INC16_MAX_W, "INC16 variants");
     constexpr int NDM = INC16 ? (W + 1) / 2 : 0;    // statistics increments from the profile (PcRow): their dwords per lane per residue row
     constexpr int RS = pc_prof_row_dwords(W, INC16);   // row stride: scores, then increments
     constexpr int ROWS = pc_prof_rows(INC16);       // residue rows: 24, + 1 for "any other byte" (scores as '*', identical to nothing)
     // A stream entry's high half is its profile row's offset: in bytes where the largest one fits 16 bits (then one SDWA add
-    // makes the row's LDS address), in dwords otherwise (shift + add).  INC16 classes have segments of at most 32 lanes,
-    // i.e. at least 2 rows per 64-dword line
+    // makes the row's LDS address), in dwords otherwise (shift + add: W >= 48 only).  The profile cell's tables are 3 x the
+    // size, so they are laid out for at most 32 lanes per segment -- at least 2 rows per 64-dword line, which keeps the byte
+    // offsets; a 64-lane segment (percent-positives runs on long column genes only) uses two such half tables, lanes 0-31
+    // the first, lanes 32-63 the second
     constexpr bool BYTE_OFF = ((INC16 ? (ROWS + 1) / 2 : ROWS) * RS * 256) < 65536;
+    static_assert(!INC16 || BYTE_OFF, "profile-cell tables must keep byte offsets");
     // one dynamic LDS array (16-byte aligned): score table | 4 private wave regions | shared profile
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     const int lane = threadIdx.x & 63;
     int8_t (*tab)[24] = (int8_t(*)[24])smem;                         // [24][24]            576 B
     // The profile, shared by the workgroup's waves: residue row r, strip dword q, lane position k sit at dword
-    // ((r / rpl) * RS + q) * 64 + (r % rpl) * Gb + k, with Gb = the class's lanes-per-segment bound (8..64) and
-    // rpl = 64 / Gb rows per 64-dword line.  A strip dword's q-stride is 256 B, a compile-time immediate of the LDS
+    // ((r / rpl) * RS + q) * 64 + (r % rpl) * Gl + k, with Gl = the class's lanes-per-segment bound (8..64; profile cell:
+    // at most 32, see BYTE_OFF) and rpl = 64 / Gl rows per 64-dword line.  A strip dword's q-stride is 256 B, a compile-time immediate of the LDS
     // reads, and a lane's bank is (r % rpl) * Gb + k whatever it reads: the lanes of one segment never collide, lanes of
     // different segments only when their rows differ yet agree mod rpl (a lane-major table put all 64 lanes on random banks)
     // profile bytes: 4 * (S + 12) (the bias note above, scaled to the score field of `hi`) + what turns the stored Ho's tag into DIAG's
@@ -290,9 +293,11 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     const int lb = d.gene_len[tk.gene];
     const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
     const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
-    const int Gb = G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)), rpl = 64 / Gb;
-    const int rpl_sh = 6 - (Gb == 8 ? 3 : (Gb == 16 ? 4 : (Gb == 32 ? 5 : 6)));       // log2(rpl): no division in row_part
-    auto row_part = [&](uint32_t r) { return ((r >> rpl_sh) * (uint32_t)(RS * 64) + (r & (uint32_t)(rpl - 1)) * (uint32_t)Gb) * (BYTE_OFF ? 4u : 1u); };   // entry units (dword index where it indexes `prof`: see the build loop)
+    const int Gb = G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64));
+    const int Gl = (INC16 && Gb == 64) ? 32 : Gb, rpl = 64 / Gl;                  // lanes per (half) table, rows per line
+    const int rpl_sh = 6 - (Gl == 8 ? 3 : (Gl == 16 ? 4 : (Gl == 32 ? 5 : 6)));       // log2(rpl): no division in row_part
+    const uint32_t half_dw = (INC16 && Gb == 64) ? (uint32_t)(((ROWS + 1) / 2) * RS * 64) : 0u;   // where the second half table starts
+    auto row_part = [&](uint32_t r) { return ((r >> rpl_sh) * (uint32_t)(RS * 64) + (r & (uint32_t)(rpl - 1)) * (uint32_t)Gl) * (BYTE_OFF ? 4u : 1u); };   // entry units (dword index where it indexes `prof`: see the build loop)
     const int nseg = min(64 / G, PC_MAX_SEG);
     const int NS = NWV * nseg;                      // row slots of the workgroup
     // LDS: score table | the waves' private regions (sized by nseg) | the shared profile
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     const bool is_head = in_seg && k == 0;
     const int k_out = (lb - 1) / W, c_out = (lb - 1) - k_out * W;
     const bool is_out = in_seg && k == k_out;
+    const uint32_t kcol = (uint32_t)(k < Gl ? k : k - Gl) + (k < Gl ? 0u : half_dw);   // my column of the profile (second half table for lanes >= 32 of a 64-lane segment)
     const int R = tk.end - tk.begin;                // rows (alignments) of this workgroup task, <= PC_TASK_ROWS
     // wave-local row lr <-> task row (lr / nseg) * NS + wv * nseg + lr % nseg  (monotone in lr)
     auto task_row = [&](int lr) { return (lr / nseg) * NS + wv * nseg + (lr % nseg); };
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
                     const int c = q * 4 + e;
                     if (c < W) v |= (uint32_t)(uint8_t)tab[min(r, 23)][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
                 }
-                prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + q * 64 + k] = v;
+                prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + q * 64 + kcol] = v;
             }
             if constexpr (INC16) {
                 // a column whose residue is "another byte" (code >= 24) never gets here: the host sends such column genes
@@ -349,9 +355,13 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int c = q * 2 + e;
-                        if (c < W) v |= (PC_INC16_K + (uint32_t)(r < 24 && (int)((bc[c >> 2] >> (8 * (c & 3))) & 0xffu) == r)) << (16 * e);
+                        // ppos (metrics.py:218-220): "positive" columns count too -- matrix score > 0 (read back from the LDS score
+                        // table: 4 * (S + 12) + tag shift), which for two bytes outside the alphabet ('*' against '*': +1) also
+                        // covers their identity, so this table is exact for any byte
+                        const int bcode = (int)((bc[c >> 2] >> (8 * (c & 3))) & 0xffu);
+                        if (c < W) v |= (PC_INC16_K + (uint32_t)((r < 24 && bcode == r) || (ppos && (int)tab[min(r, 23)][min(bcode, 23)] > 48 + (PcTag<RULE>::tD - PcTag<RULE>::tOF)))) << (16 * e);
                     }
-                    prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + (ND + q) * 64 + k] = v;
+                    prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + (ND + q) * 64 + kcol] = v;
                 }
             }
         }
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     const uint32_t K = 0x10000u;
     const int half = lane / PC_WIN, hl = lane % PC_WIN;               // refill: which of the pass's segments, which entry
     // LDS byte address of my column of the profile
-    const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + (uint32_t)(in_seg ? k : 0) * 4u;
+    const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + (in_seg ? kcol : 0u) * 4u;
     const uint32_t ring_lane = (uint32_t)(in_seg ? seg : 0) * PC_WIN;
 
     // Stage PC_WIN stream entries of every segment starting at stream position `base` (64 / PC_WIN segments per pass).
@@ -508,6 +518,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
         // Flags are rare (two entries per row, and only a head lane or the output lane acts on them): one compare per step,
         // the two that tell them apart only when it fires
         unsigned long long rstm = 0, lastm = 0;
+        asm volatile("" : "+s"(anym));                                    // scalar test (left alone, the compiler carries it as a lane mask: one VALU compare per step)
         if (anym != 0)
             asm volatile("v_cmp_lt_u32_sdwa %0, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"       // RESET: flag byte > 1 (K.BYTE_2 == 1)
                          "v_cmp_eq_u32_sdwa %1, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"       // LAST:  flag byte == 1
@@ -551,12 +562,12 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
 // needs to instantiate (explicitly, in pc_nw_rules.hip; implicitly for rules 0 and 1 in pc_nw.hip).
 template <int W, int RULE, bool INC16>
 int pc_systolic_launch(unsigned ntasks, int nw, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks,
-                       const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res) {
-    hipLaunchKernelGGL((k_nw_systolic<W, RULE, INC16>), dim3(ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res);
+                       const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos) {
+    hipLaunchKernelGGL((k_nw_systolic<W, RULE, INC16>), dim3(ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res, ppos);
     return (int)hipGetLastError();
 }
 
 // X-macro over the compiled widths: PC_FOR_W2(M) for those that exist with both cells, PC_FOR_W1(M) for the wide ones
 #define PC_FOR_W2(M) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(22) M(24)
 #define PC_FOR_W1(M) M(32) M(48) M(64)
-#define PC_SYSTOLIC_SIG (unsigned, int, size_t, hipStream_t, const PcDev&, const PcTask*, const int32_t*, const uint32_t*, uint2*)
+#define PC_SYSTOLIC_SIG (unsigned, int, size_t, hipStream_t, const PcDev&, const PcTask*, const int32_t*, const uint32_t*, uint2*, int)

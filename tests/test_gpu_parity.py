@@ -459,6 +459,32 @@ def test_aai_percent_positives(gpu_ctx, native_built, small_genomes, small_packe
         assert average_aminoacid_identity(small_genomes[s], small_genomes[t], True, True) == O.py_aai(small_genomes[s], small_genomes[t], True, True)
 
 
+def test_percent_positives_on_the_systolic_kernel(gpu_ctx, native_built):
+    """aai with ppos=True at some size: the launch classes whose profile cell can run (segments of up to 32 lanes, W <= 24)
+    take "identical or positive" from the 16-bit increment table, the others fall back to the general kernel; column
+    genes with bytes outside the alphabet included ('*' against '*' scores +1, so the table is exact for them too)."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    pk = synth_packed(150, 900, seed=21)
+    gpu_ctx.upload(pk)
+    got, st = gpu_ctx.fill("aai_ppos", True, want_stats=True)
+    assert np.array_equal(got, O.fill(pk, "aai_ppos", True))
+    assert st["n_align_launches"] > 3
+    rng = np.random.default_rng(8)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY" * 3 + "BZX*UJ"))
+    genomes = []
+    for gi in range(8):
+        g = Genome(f"g{gi}")
+        for p in range(5):
+            g.add(f"pham{p}", "".join(aa[rng.integers(0, aa.size, int(rng.integers(3, 1500)))]))
+        genomes.append(g)
+    pk2 = pack_genomes(genomes)
+    gpu_ctx.upload(pk2)
+    assert np.array_equal(gpu_ctx.fill("aai_ppos", False), O.fill(pk2, "aai_ppos", False))
+
+
 def test_matrix_de_novo_drop_in(native_built, small_genomes):
     """The reference-shaped entry point: matrix_de_novo(genomes, METRICS[m], cpus)."""
     from phamclust_amd.cli import METRICS

@@ -282,3 +282,19 @@ def test_fill_rows_is_a_prefix(O, small_packed):
     n = small_packed.n_genomes
     k = sum(n - 1 - s for s in range(5))
     assert np.array_equal(part[:k], full[:k]) and n_aln > 0 and n_cells > n_aln
+
+
+def test_bulk_fill_equals_pairwise_for_every_metric():
+    """pco_fill (OpenMP over the condensed index) and pco_pair answer alike for all seven selectors, percent-positives
+    (aai, ppos=True: metrics.py:218-220) included -- the bulk path once treated that one as peq."""
+    import numpy as np
+    from oracle import oracle as O
+    from phamclust_amd.synth import synth_packed
+    pk = synth_packed(11, 150, seed=5)
+    n = pk.n_genomes
+    for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
+        for as_distance in (True, False):
+            f = O.fill(pk, metric, as_distance)
+            want = np.array([O.pair(pk, metric, s, t, as_distance=as_distance) for s in range(n) for t in range(s + 1, n)])
+            assert np.array_equal(f, want), (metric, as_distance)
+    assert (O.fill(pk, "aai_ppos", False) >= O.fill(pk, "aai", False)).all()
