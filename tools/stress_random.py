@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised stress of all six metrics against the oracle on many small collections (paralogs, byte-identical
+"""Randomised stress of all six metrics (and aai with ppos=True) against the oracle on many small collections (paralogs, byte-identical
 sequences, odd residues, tie-heavy 3-letter sequences, lengths up to 1,500), every collection under a randomly chosen
 row of the tie-rule table (kernel and oracle switched together): `python tools/stress_random.py SEED TRIALS`.
 r01: seed 4242, 1,500 collections, 9,000 fills, 0 mismatches; seed 20261004, 4,000 collections, 24,000 fills, 0 mismatches.
@@ -36,7 +36,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
         genomes.append(genome)
     packed = pack_genomes(genomes)
     ctx.upload(packed)
-    for metric in ("gcs", "jc", "pocp", "af", "aai", "peq"):
+    for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
         got = ctx.fill(metric, as_distance=bool(trial & 1))
         want = O.fill(packed, metric, as_distance=bool(trial & 1))
         if not np.array_equal(got, want):
