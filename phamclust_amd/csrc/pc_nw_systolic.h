@@ -284,8 +284,9 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     // The profile, shared by the workgroup's waves: residue row r, strip dword q, lane position k sit at dword
     // ((r / rpl) * RS + q) * 64 + (r % rpl) * Gl + k, with Gl = the class's lanes-per-segment bound (8..64; profile cell:
     // at most 32, see BYTE_OFF) and rpl = 64 / Gl rows per 64-dword line.  A strip dword's q-stride is 256 B, a compile-time immediate of the LDS
-    // reads, and a lane's bank is (r % rpl) * Gb + k whatever it reads: the lanes of one segment never collide, lanes of
-    // different segments only when their rows differ yet agree mod rpl (a lane-major table put all 64 lanes on random banks)
+    // reads, a row's offset fits the 16 bits of a stream entry's high half, and a lane's bank is (r % rpl) * Gl + k whatever
+    // it reads: the lanes of one segment never collide, lanes of different segments when their rows differ yet agree mod rpl
+    // (measured: the conflict counters read the same as with a lane-major table, and LDS waits are ~1 % of the kernel)
     // profile bytes: 4 * (S + 12) (the bias note above, scaled to the score field of `hi`) + what turns the stored Ho's tag into DIAG's
     for (int i = threadIdx.x; i < 576; i += 64 * NWV) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
 
