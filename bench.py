@@ -164,7 +164,7 @@ def main():
     import torch
     import torch.distributed as dist
     from phamclust_amd import build, hip
-    from phamclust_amd.distributed import fill_distributed
+    from phamclust_amd.distributed import dist_mode, fill_distributed
     from phamclust_amd.synth import synth_packed
 
     # PC_BENCH_BACKEND=gloo rehearses the N>1 flow on a box with fewer GPUs than ranks (ranks share devices, the
@@ -189,6 +189,7 @@ def main():
     ctx = hip.Context(local_rank)
     ctx.upload(packed)
     n_pairs = packed.n_pairs
+    sliced = world > 1 and dist_mode() == "alignments" and a.metric in ("aai", "peq")     # PHAMCLUST_DIST_MODE=alignments
 
     def step():
         if world == 1:
@@ -238,8 +239,11 @@ def main():
         ms_dev = sum(s["ms_total"] for s in stats) / len(stats)
         align_span = None
     else:
-        n_aln = int(agg_sum[-1, 0]); n_cells = int(agg_sum[-1, 1]); n_rbytes = int(agg_sum[-1, 2])
-        n_daln = int(agg_sum[-1, 6]); n_dcells = int(agg_sum[-1, 7])
+        # "pairs" mode: every rank reports its shard, the job is the sum; "alignments" mode: every rank plans the whole
+        # fill and reports the whole job's counts
+        whole = agg_max if sliced else agg_sum
+        n_aln = int(whole[-1, 0]); n_cells = int(whole[-1, 1]); n_rbytes = int(whole[-1, 2])
+        n_daln = int(whole[-1, 6]); n_dcells = int(whole[-1, 7])
         ms_align = float(agg_max[:, 4].mean()) / 1e3          # slowest rank's alignment time per step
         ms_dev = float(agg_max[:, 5].mean()) / 1e3
         align_span = [float(agg_min[:, 4].mean()) / 1e3, float(agg_max[:, 4].mean()) / 1e3]
@@ -251,7 +255,8 @@ def main():
         "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill",
                    "n_genomes": a.genomes, "n_phams": packed.n_phams, "metric_selector": a.metric, "genome_pairs": n_pairs,
                    "n_genes": packed.n_genes, "n_residues": int(packed.residues.size),
-                   "parallelism": f"static pair shard over {world} GPU(s)" + (" + 1 RCCL gather + device assembly" if world > 1 else "")
+                   "parallelism": (f"alignments sliced over {world} GPUs (every rank plans the whole fill) + 1 RCCL reduce of their results + matrix on rank 0"
+                                   if sliced else f"static pair shard over {world} GPU(s)" + (" + 1 RCCL gather + device assembly" if world > 1 else ""))
                                   + ("" if backend == "nccl" or world == 1 else f" [REHEARSAL: backend {backend}, ranks share GPUs]")},
     }
     if a.metric in ("aai", "peq"):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PC_VERSION 120   /* 0.2.0: tie-rule table (pc_set_tie_rule), pinned-host fills */
+#define PC_VERSION 130   /* 0.2.0: tie-rule table (pc_set_tie_rule), pinned-host fills */
 
 typedef enum {
     PC_OK = 0,
@@ -143,6 +143,23 @@ int pc_fill_shard_dev(pc_ctx* ctx, int metric, int as_distance, void* shard_dev,
 /* Root only: permute `world` gathered shards (f64[world * pc_shard_stride()], device)
  * into scipy condensed order (device f64[N(N-1)/2]). */
 int pc_assemble_dev(pc_ctx* ctx, const void* gathered_dev, int world, void* out_condensed_dev, void* stream);
+
+/*
+ * Alignment-sliced multi-GPU route for aai / peq (replaces, like pc_fill_shard_dev + the gather, the joblib fan-out of
+ * matrix.py:432-497 -- but splits the ALIGNMENTS, not the genome pairs): every rank holds the same upload, unsharded, and
+ *   1. pc_plan_dev        plans the whole fill (identical on every rank; stats->n_distinct_alignments = length of `res`),
+ *   2. pc_align_slice_dev aligns every slice_world-th task of each launch class starting at slice_rank and writes
+ *                         (n_ident, aln_len) pairs -- 8 bytes per distinct alignment -- into res_dev, zeros elsewhere,
+ *   3. the caller sums the ranks' res arrays onto the root (one reduce; as 64-bit integers: exactly one rank contributes
+ *      a non-zero entry), and
+ *   4. pc_reduce_dev      on the root turns the summed res into the condensed matrix.
+ * Every distinct (row sequence, column sequence) pair is aligned once per JOB (the pair-sharded route merges duplicates
+ * per rank only) and the ranks' work is equal by construction.  The plan stays valid until the next upload, shard change
+ * or fill on the context.  metric: PC_AAI, PC_PEQ or PC_AAI_PPOS.
+ */
+int pc_plan_dev(pc_ctx* ctx, int metric, void* stream, pc_stats* stats);
+int pc_align_slice_dev(pc_ctx* ctx, int slice_rank, int slice_world, void* res_dev, void* stream, pc_stats* stats);
+int pc_reduce_dev(pc_ctx* ctx, int metric, int as_distance, const void* res_dev, void* out_condensed_dev, void* stream);
 
 /*
  * Test hook for the alignment kernels (replaces parasail.nw_trace_diag_16 +

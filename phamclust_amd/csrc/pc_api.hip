@@ -100,8 +100,14 @@ struct pc_ctx {
     DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
-    DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut;
+    DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut, b_slice_begin;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
+    // what the last alignment plan (stage_plan) left in the work buffers, for the stages that follow it
+    struct PlanState {
+        bool valid = false; int ppos = 0; int condensed = 1; int64_t A = 0, n_distinct = 0; uint32_t ntasks = 0;
+        std::vector<uint32_t> tb;           // [ncls+1] task range per launch class in b_tasks_sorted
+        pc_stats st;                        // counts of the plan (alignments, cells, tasks, distinct ...)
+    } plan;
     double* h_out = nullptr; size_t h_out_cap = 0;   // pinned result buffer lent out by pc_fill_borrow (grow-only)
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -180,7 +186,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_tasks_sorted, &c->b_bucket_row, &c->b_bucket_dest,
-                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut};
+                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut, &c->b_slice_begin};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < pc_ctx::kAux; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -223,6 +229,7 @@ static int pc_class_variant(int cls) { const int nvar = pc_nw_num_variants(); re
 static int pc_class_compare_only(int cls) { const int nvar = pc_nw_num_variants(); return cls >= nvar * 4 && cls < nvar * 8; }
 
 static int apply_shard(pc_ctx* c, int rank, int world) {
+    c->plan.valid = false;                             // a plan belongs to the shard it was made for
     const int N = c->dev.N;
     std::vector<int32_t> owned; std::vector<int64_t> lbase;
     c->h_t_rank.assign(std::max(N, 1), 0); c->h_t_lbase.assign(std::max(N, 1), 0);
@@ -273,7 +280,7 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         tick = now;
     };
     if ((rc = wait_last_fill(c, nullptr, false))) return rc;
-    c->uploaded = false; c->target_cost.clear();
+    c->uploaded = false; c->target_cost.clear(); c->plan.valid = false;
     PC_HIP(hipStreamSynchronize(c->stream));
 
     // ---- host-side indices -------------------------------------------------------
@@ -558,7 +565,7 @@ extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? 
 // independent (disjoint result slots), so their launches are spread over the caller's stream and
 // seven auxiliary streams: the drain of one class overlaps the next one's start.
 static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[ncls_all+1]*/, const int32_t* cls_max_lb,
-                             hipStream_t st, pc_stats* stats, int ppos) {
+                             uint2* res, hipStream_t st, pc_stats* stats, int ppos) {
     const int ncls = c->ncls_all;
     auto variant_of = [&](int cls) { return pc_class_variant(cls); };
     std::vector<int> order;
@@ -591,7 +598,7 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         // launches that use the one scratch slab stay in order on the caller's stream
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
-                              nullptr /* result slot = position in the sorted list */, c->b_res.as<uint2>(), variant < 0 ? c->b_scratch.p : nullptr,
+                              nullptr /* result slot = position in the sorted list */, res, variant < 0 ? c->b_scratch.p : nullptr,
                               variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, c->tie_rule, pc_class_compare_only(i), ls);
         if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
@@ -604,6 +611,139 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         PC_HIP(hipStreamWaitEvent(st, c->aux_ev[k], 0));
     }
     return first_error;
+}
+
+// ---- the three stages of an aai / peq fill.  pc_fill* run them back to back; the alignment-sliced multi-GPU route
+// (pc_plan_dev, pc_align_slice_dev, pc_reduce_dev) runs them with a collective between the last two.
+
+// PLAN: COUNT, ENUM, sort, distinct alignments, tasks sorted by launch class.  Leaves its results in the context's work
+// buffers and c->plan; three small read-backs.
+static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st) {
+    int rc = PC_OK;
+    const PcDev& d = c->dev;
+    const int64_t Lp = c->shard_pairs;
+    pc_ctx::PlanState& P = c->plan;
+    P.valid = false; P.ppos = ppos; P.condensed = condensed; P.A = 0; P.n_distinct = 0; P.ntasks = 0; P.tb.assign(c->ncls_all + 1, 0);
+    memset(&P.st, 0, sizeof(P.st));
+    pc_stats& local = P.st;
+    local.n_pairs = Lp;
+    if (d.G > 0 && c->min_gene_len == 0) {
+        pc_set_error("fill: an empty translation cannot be aligned (aai/peq); the reference fails on it too"); return PC_ERR_DATA;
+    }
+    const int U = d.U;
+    const int ncls = c->ncls_all;
+    const int64_t tmp_fixed = std::max<int64_t>(Lp + 1, U + 1);
+    if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_start_q.ensure((U + 1) * 4)) ||
+        (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) || (rc = c->b_task_off_q.ensure((U + 1) * 4)) ||
+        (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(tmp_fixed) * 4)) || (rc = c->b_totals.ensure(64)) || (rc = c->b_plan.ensure(4096)))
+        return rc;
+    // 1 COUNT: alignments per pair (the reference's loop nest, metrics.py:204-224), totals
+    PC_HIP(hipMemsetAsync(c->b_na.p, 0, (Lp + 1) * 4, st));
+    PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, st));
+    PcWalkArgs a; memset(&a, 0, sizeof(a));
+    a.na = c->b_na.as<uint32_t>(); a.totals = c->b_totals.as<unsigned long long>();
+    a.as_distance = 0; a.condensed = condensed;
+    if ((rc = pc_launch_walk(PCW_COUNT, d, c->shard, a, st))) return rc;
+    if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(),
+                                    (int64_t)(c->b_scan_tmp.cap / 4), st))) return rc;
+    uint64_t* h_tot = (uint64_t*)(c->h_plan + 1000);
+    PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 24, hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));                                     // first read-back: the batch size
+    const uint64_t A = h_tot[0];
+    P.A = (int64_t)A;
+    if (A >= 0x7fffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^31-1 per-call limit; shard the job (pc_set_shard)", (unsigned long long)A); return PC_ERR_LIMIT; }
+    local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2];
+    a.off = c->b_off.as<uint32_t>();
+    if (A > 0) {
+        const int64_t An = (int64_t)A;
+        const int key_bits = 2 * d.ubits;
+        const size_t sort_bytes = pc_sort_temp_bytes(An, key_bits);
+        if ((rc = c->b_key0.ensure(A * 8)) || (rc = c->b_key1.ensure(A * 8)) || (rc = c->b_val0.ensure(A * 4)) || (rc = c->b_val1.ensure(A * 4)) ||
+            (rc = c->b_sort_tmp.ensure(std::max<size_t>(sort_bytes, 16))) || (rc = c->b_flags.ensure((A + 1) * 4)) || (rc = c->b_excl.ensure((A + 1) * 4)) ||
+            (rc = c->b_alias.ensure(A * 4)) || (rc = c->b_bucket_row.ensure(A * 4)) || (rc = c->b_res.ensure(A * 8)) ||
+            (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(std::max<int64_t>(tmp_fixed, An + 1)) * 4)))
+            return rc;
+        const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
+        // 2 ENUM: one sort key per alignment slot; 3 sort; 4 distinct alignments, aliases, buckets (pc_plan.hip)
+        a.key = c->b_key0.as<unsigned long long>(); a.val = c->b_val0.as<uint32_t>();
+        if ((rc = pc_launch_walk(PCW_ENUM, d, c->shard, a, st))) return rc;
+        if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
+                                c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), An, key_bits, st))) return rc;
+        if ((rc = pc_launch_mark_heads(c->b_key1.as<unsigned long long>(), c->b_flags.as<uint32_t>(), An, st))) return rc;
+        if ((rc = pc_scan_exclusive_u32(c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(), An + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+        PC_HIP(hipMemsetAsync(c->b_start_q.p, 0, (U + 1) * 4, st));
+        PC_HIP(hipMemsetAsync(c->b_end_q.p, 0, (U + 1) * 4, st));
+        if ((rc = pc_launch_unique(d, c->b_key1.as<unsigned long long>(), c->b_val1.as<uint32_t>(), c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(),
+                                   c->b_alias.as<uint32_t>(), c->b_bucket_row.as<int32_t>(), c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(),
+                                   c->b_totals.as<unsigned long long>(), An, st))) return rc;
+        // 5 workgroup tasks per column sequence (a bucket's left-over rows may go to a narrower variant); second
+        //   read-back: number of tasks, distinct totals
+        if ((rc = pc_launch_task_count(c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->task_plan, c->b_ntask_q.as<uint32_t>(), U, st))) return rc;
+        if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), U + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
+        PC_HIP(hipMemcpyAsync(c->h_plan, c->b_task_off_q.as<uint32_t>() + U, 4, hipMemcpyDeviceToHost, st));
+        PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 40, hipMemcpyDeviceToHost, st));
+        PC_HIP(hipStreamSynchronize(st));
+        const uint32_t ntasks = c->h_plan[0];
+        local.n_tasks = ntasks; local.n_distinct_alignments = (int64_t)h_tot[3]; local.n_distinct_cells = (int64_t)h_tot[4];
+        P.ntasks = ntasks; P.n_distinct = (int64_t)h_tot[3];
+        int cbits = 1; while ((1 << cbits) < ncls) ++cbits;
+        const size_t tb_bytes = pc_sort_temp_bytes((int64_t)std::max<uint32_t>(ntasks, 1), 32 + cbits);
+        if ((rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))) || (rc = c->b_tasks_sorted.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))) ||
+            (rc = c->b_key0.ensure((size_t)ntasks * 8)) || (rc = c->b_key1.ensure((size_t)ntasks * 8)) || (rc = c->b_val0.ensure((size_t)ntasks * 4)) ||
+            (rc = c->b_val1.ensure((size_t)ntasks * 4)) || (rc = c->b_sort_tmp.ensure(std::max<size_t>(tb_bytes, 16))))
+            return rc;
+        if ((rc = pc_launch_task_fill(d, c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->task_plan,
+                                      c->b_task_off_q.as<uint32_t>(), c->b_tasks.as<PcTask>(), U, st))) return rc;
+        // 6 the task list sorted by (launch class, longest first) with the same radix sort (the key/value buffers of the
+        //   alignment sort are free again); third read-back: task range and longest column per launch class
+        if ((rc = pc_launch_task_keys(d, c->b_tasks.as<PcTask>(), c->b_key0.as<unsigned long long>(),
+                                      c->b_val0.as<uint32_t>(), (int)ntasks, st))) return rc;
+        if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
+                                c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), (int64_t)ntasks, 32 + cbits, st))) return rc;
+        if ((rc = pc_launch_task_gather(c->b_tasks.as<PcTask>(), c->b_val1.as<uint32_t>(), c->b_tasks_sorted.as<PcTask>(), (int)ntasks, st))) return rc;
+        if ((rc = pc_launch_class_bounds(c->b_key1.as<unsigned long long>(), (int)ntasks, ncls, c->b_cls_begin.as<uint32_t>(), st))) return rc;
+        PC_HIP(hipMemcpyAsync(c->h_plan, c->b_cls_begin.p, (size_t)(ncls + 1) * 4, hipMemcpyDeviceToHost, st));
+        PC_HIP(hipStreamSynchronize(st));
+        P.tb.assign(c->h_plan, c->h_plan + ncls + 1);
+    }
+    P.valid = true;
+    return PC_OK;
+}
+
+// ALIGN: the K4 launches over the planned tasks -- all of them, or every world-th task of each launch class starting at
+// slice_rank (tasks of a class are sorted longest first, so the slices of a class carry equal work); results go to
+// res[position of the distinct alignment], entries of tasks outside the slice are left zero.
+static int stage_align(pc_ctx* c, int slice_rank, int slice_world, uint2* res, hipStream_t st, pc_stats* stats) {
+    pc_ctx::PlanState& P = c->plan;
+    if (!P.valid) { pc_set_error("align: no plan (pc_plan_dev first)"); return PC_ERR_STATE; }
+    if (P.A <= 0 || P.ntasks == 0) return PC_OK;
+    int rc = PC_OK;
+    const int ncls = c->ncls_all;
+    const PcTask* task_list = c->b_tasks_sorted.as<PcTask>();
+    std::vector<uint32_t> tb = P.tb;
+    if (slice_world > 1) {
+        std::vector<uint32_t> sb(ncls + 1, 0);
+        for (int i = 0; i < ncls; ++i) {
+            const uint32_t n = P.tb[i + 1] - P.tb[i];
+            sb[i + 1] = sb[i] + (n > (uint32_t)slice_rank ? (n - (uint32_t)slice_rank + (uint32_t)slice_world - 1) / (uint32_t)slice_world : 0u);
+        }
+        if ((rc = upload_vec(c->b_slice_begin, sb))) return rc;
+        if ((rc = pc_launch_task_slice(task_list, (int)P.ntasks, c->b_cls_begin.as<uint32_t>(), c->b_slice_begin.as<uint32_t>(), slice_rank, slice_world,
+                                       c->b_tasks.as<PcTask>(), st))) return rc;       // (b_tasks: the unsorted list, free again)
+        PC_HIP(hipMemsetAsync(res, 0, (size_t)std::max<int64_t>(P.n_distinct, 1) * 8, st));
+        task_list = c->b_tasks.as<PcTask>(); tb = sb;
+    }
+    return run_align_classes(c, task_list, tb.data(), c->cls_max_lb.data(), res, st, stats, P.ppos);
+}
+
+// REDUCE: best match per anchor gene through the aliases, fp64 epilogue (metrics.py:204-232, 247-253)
+static int stage_reduce(pc_ctx* c, int metric, int as_distance, const uint2* res, double* out, hipStream_t st) {
+    pc_ctx::PlanState& P = c->plan;
+    if (!P.valid) { pc_set_error("reduce: no plan (pc_plan_dev first)"); return PC_ERR_STATE; }
+    PcWalkArgs a; memset(&a, 0, sizeof(a));
+    a.off = c->b_off.as<uint32_t>(); a.alias = c->b_alias.as<uint32_t>(); a.res = res; a.out = out;
+    a.as_distance = as_distance ? 1 : 0; a.condensed = P.condensed;
+    return pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, c->dev, c->shard, a, st);
 }
 
 static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
@@ -642,94 +782,13 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
     } else {
-        if (d.G > 0 && c->min_gene_len == 0) {
-            pc_set_error("fill: an empty translation cannot be aligned (aai/peq); the reference fails on it too"); return PC_ERR_DATA;
-        }
-        const int U = d.U;
-        const int ncls = c->ncls_all;
-        const int64_t tmp_fixed = std::max<int64_t>(Lp + 1, U + 1);
-        if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_start_q.ensure((U + 1) * 4)) ||
-            (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) || (rc = c->b_task_off_q.ensure((U + 1) * 4)) ||
-            (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(tmp_fixed) * 4)) || (rc = c->b_totals.ensure(64)) || (rc = c->b_plan.ensure(4096)))
-            return rc;
-        // 1 COUNT: alignments per pair (the reference's loop nest, metrics.py:204-224), totals
-        PC_HIP(hipMemsetAsync(c->b_na.p, 0, (Lp + 1) * 4, st));
-        PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, st));
-        PcWalkArgs a; memset(&a, 0, sizeof(a));
-        a.na = c->b_na.as<uint32_t>(); a.totals = c->b_totals.as<unsigned long long>();
-        a.as_distance = as_distance; a.condensed = condensed;
-        if ((rc = pc_launch_walk(PCW_COUNT, d, c->shard, a, st))) return rc;
-        if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(),
-                                        (int64_t)(c->b_scan_tmp.cap / 4), st))) return rc;
-        uint64_t* h_tot = (uint64_t*)(c->h_plan + 1000);
-        PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 24, hipMemcpyDeviceToHost, st));
-        PC_HIP(hipStreamSynchronize(st));                                     // first read-back: the batch size
-        const uint64_t A = h_tot[0];
-        if (A >= 0x7fffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^31-1 per-call limit; shard the job (pc_set_shard)", (unsigned long long)A); return PC_ERR_LIMIT; }
-        local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2];
-        a.off = c->b_off.as<uint32_t>();
-        if (A > 0) {
-            const int64_t An = (int64_t)A;
-            const int key_bits = 2 * d.ubits;
-            const size_t sort_bytes = pc_sort_temp_bytes(An, key_bits);
-            if ((rc = c->b_key0.ensure(A * 8)) || (rc = c->b_key1.ensure(A * 8)) || (rc = c->b_val0.ensure(A * 4)) || (rc = c->b_val1.ensure(A * 4)) ||
-                (rc = c->b_sort_tmp.ensure(std::max<size_t>(sort_bytes, 16))) || (rc = c->b_flags.ensure((A + 1) * 4)) || (rc = c->b_excl.ensure((A + 1) * 4)) ||
-                (rc = c->b_alias.ensure(A * 4)) || (rc = c->b_bucket_row.ensure(A * 4)) || (rc = c->b_res.ensure(A * 8)) ||
-                (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(std::max<int64_t>(tmp_fixed, An + 1)) * 4)))
-                return rc;
-            const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
-            // 2 ENUM: one sort key per alignment slot; 3 sort; 4 distinct alignments, aliases, buckets (pc_plan.hip)
-            a.key = c->b_key0.as<unsigned long long>(); a.val = c->b_val0.as<uint32_t>();
-            if ((rc = pc_launch_walk(PCW_ENUM, d, c->shard, a, st))) return rc;
-            if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
-                                    c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), An, key_bits, st))) return rc;
-            if ((rc = pc_launch_mark_heads(c->b_key1.as<unsigned long long>(), c->b_flags.as<uint32_t>(), An, st))) return rc;
-            if ((rc = pc_scan_exclusive_u32(c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(), An + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-            PC_HIP(hipMemsetAsync(c->b_start_q.p, 0, (U + 1) * 4, st));
-            PC_HIP(hipMemsetAsync(c->b_end_q.p, 0, (U + 1) * 4, st));
-            if ((rc = pc_launch_unique(d, c->b_key1.as<unsigned long long>(), c->b_val1.as<uint32_t>(), c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(),
-                                       c->b_alias.as<uint32_t>(), c->b_bucket_row.as<int32_t>(), c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(),
-                                       c->b_totals.as<unsigned long long>(), An, st))) return rc;
-            // 5 workgroup tasks per column sequence (a bucket's left-over rows may go to a narrower variant); second
-            //   read-back: number of tasks, distinct totals
-            if ((rc = pc_launch_task_count(c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->task_plan, c->b_ntask_q.as<uint32_t>(), U, st))) return rc;
-            if ((rc = pc_scan_exclusive_u32(c->b_ntask_q.as<uint32_t>(), c->b_task_off_q.as<uint32_t>(), U + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
-            PC_HIP(hipMemcpyAsync(c->h_plan, c->b_task_off_q.as<uint32_t>() + U, 4, hipMemcpyDeviceToHost, st));
-            PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 40, hipMemcpyDeviceToHost, st));
-            PC_HIP(hipStreamSynchronize(st));
-            const uint32_t ntasks = c->h_plan[0];
-            local.n_tasks = ntasks; local.n_distinct_alignments = (int64_t)h_tot[3]; local.n_distinct_cells = (int64_t)h_tot[4];
-            int cbits = 1; while ((1 << cbits) < ncls) ++cbits;
-            const size_t tb_bytes = pc_sort_temp_bytes((int64_t)std::max<uint32_t>(ntasks, 1), 32 + cbits);
-            if ((rc = c->b_tasks.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))) || (rc = c->b_tasks_sorted.ensure(std::max<uint32_t>(ntasks, 1) * sizeof(PcTask))) ||
-                (rc = c->b_key0.ensure((size_t)ntasks * 8)) || (rc = c->b_key1.ensure((size_t)ntasks * 8)) || (rc = c->b_val0.ensure((size_t)ntasks * 4)) ||
-                (rc = c->b_val1.ensure((size_t)ntasks * 4)) || (rc = c->b_sort_tmp.ensure(std::max<size_t>(tb_bytes, 16))))
-                return rc;
-            if ((rc = pc_launch_task_fill(d, c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(), c->task_plan,
-                                          c->b_task_off_q.as<uint32_t>(), c->b_tasks.as<PcTask>(), U, st))) return rc;
-            // 6 the task list sorted by (launch class, longest first) with the same radix sort (the key/value buffers of the
-            //   alignment sort are free again); third read-back: task range and longest column per launch class
-            if ((rc = pc_launch_task_keys(d, c->b_tasks.as<PcTask>(), c->b_key0.as<unsigned long long>(),
-                                          c->b_val0.as<uint32_t>(), (int)ntasks, st))) return rc;
-            if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
-                                    c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), (int64_t)ntasks, 32 + cbits, st))) return rc;
-            if ((rc = pc_launch_task_gather(c->b_tasks.as<PcTask>(), c->b_val1.as<uint32_t>(), c->b_tasks_sorted.as<PcTask>(), (int)ntasks, st))) return rc;
-            if ((rc = pc_launch_class_bounds(c->b_key1.as<unsigned long long>(), (int)ntasks, ncls, c->b_cls_begin.as<uint32_t>(), st))) return rc;
-            PC_HIP(hipMemcpyAsync(c->h_plan, c->b_cls_begin.p, (size_t)(ncls + 1) * 4, hipMemcpyDeviceToHost, st));
-            PC_HIP(hipStreamSynchronize(st));
-            const PcTask* task_list = c->b_tasks_sorted.as<PcTask>();
-            PC_HIP(hipEventRecord(c->ev[1], st));
-            // 7 K4: one result per distinct alignment, addressed by its position in the sorted list
-            std::vector<uint32_t> tb(c->h_plan, c->h_plan + ncls + 1);
-            if ((rc = run_align_classes(c, task_list, tb.data(), c->cls_max_lb.data(), st, &local, ppos))) return rc;
-            PC_HIP(hipEventRecord(c->ev[2], st));
-        } else {
-            PC_HIP(hipEventRecord(c->ev[1], st));
-            PC_HIP(hipEventRecord(c->ev[2], st));
-        }
-        // 8 REDUCE: best match per anchor gene through the aliases, fp64 epilogue
-        a.alias = c->b_alias.as<uint32_t>(); a.res = c->b_res.as<uint2>(); a.out = out;
-        if ((rc = pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, d, c->shard, a, st))) return rc;
+        if ((rc = stage_plan(c, ppos, condensed, st))) return rc;
+        PC_HIP(hipEventRecord(c->ev[1], st));
+        if ((rc = stage_align(c, 0, 1, c->b_res.as<uint2>(), st, &local))) return rc;
+        PC_HIP(hipEventRecord(c->ev[2], st));
+        if ((rc = stage_reduce(c, metric, as_distance, c->b_res.as<uint2>(), out, st))) return rc;
+        { const pc_stats& ps = c->plan.st; local.n_alignments = ps.n_alignments; local.n_cells = ps.n_cells; local.n_residue_bytes = ps.n_residue_bytes;
+          local.n_tasks = ps.n_tasks; local.n_distinct_alignments = ps.n_distinct_alignments; local.n_distinct_cells = ps.n_distinct_cells; }
         PC_HIP(hipEventRecord(c->ev[3], st));
     }
     c->busy = true; c->last_stream = st;
@@ -746,6 +805,63 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         }
         *stats = local;
     }
+    return PC_OK;
+}
+
+// ---- alignment-sliced multi-GPU route (aai / peq): every rank plans the whole (unsharded) fill -- milliseconds --, aligns
+// every world-th task of each launch class, the per-alignment results are summed to the root (entries of foreign tasks are
+// zero), and the root reduces.  Each distinct (row sequence, column sequence) pair is then aligned once in the whole JOB,
+// not once per rank, and the ranks carry equal work by construction (no cost-balanced deal, no COUNT pass for it).
+extern "C" int pc_plan_dev(pc_ctx* c, int metric, void* stream, pc_stats* stats) {
+    if (!c || !c->uploaded) { pc_set_error("pc_plan_dev: upload first"); return PC_ERR_STATE; }
+    if (metric != PC_AAI && metric != PC_PEQ && metric != PC_AAI_PPOS) { pc_set_error("pc_plan_dev: metric %d has no alignment plan", metric); return PC_ERR_ARG; }
+    if (c->world != 1) { pc_set_error("pc_plan_dev: context is sharded (%d/%d); the alignment-sliced route plans the whole matrix", c->rank, c->world); return PC_ERR_STATE; }
+    PC_ON_DEVICE(c);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = wait_last_fill(c, st, true); if (rc != PC_OK) return rc;
+    PC_HIP(hipEventRecord(c->ev[0], st));
+    if ((rc = stage_plan(c, metric == PC_AAI_PPOS, 1, st))) return rc;
+    PC_HIP(hipEventRecord(c->ev[1], st));
+    c->busy = true; c->last_stream = st;
+    if (stats) {
+        PC_HIP(hipEventSynchronize(c->ev[1]));
+        *stats = c->plan.st;
+        PC_HIP(hipEventElapsedTime(&stats->ms_plan, c->ev[0], c->ev[1]));
+        stats->ms_total = stats->ms_plan;
+    }
+    return PC_OK;
+}
+
+extern "C" int pc_align_slice_dev(pc_ctx* c, int slice_rank, int slice_world, void* res_dev, void* stream, pc_stats* stats) {
+    if (!c || !c->uploaded || !c->plan.valid) { pc_set_error("pc_align_slice_dev: pc_plan_dev first"); return PC_ERR_STATE; }
+    if (slice_world < 1 || slice_rank < 0 || slice_rank >= slice_world) { pc_set_error("pc_align_slice_dev: slice %d of %d", slice_rank, slice_world); return PC_ERR_ARG; }
+    if (!res_dev && c->plan.n_distinct > 0) { pc_set_error("pc_align_slice_dev: res_dev is NULL"); return PC_ERR_ARG; }
+    PC_ON_DEVICE(c);
+    hipStream_t st = (hipStream_t)stream;
+    pc_stats local = c->plan.st;
+    PC_HIP(hipEventRecord(c->ev[1], st));
+    int rc = stage_align(c, slice_rank, slice_world, (uint2*)res_dev, st, &local); if (rc != PC_OK) return rc;
+    PC_HIP(hipEventRecord(c->ev[2], st));
+    c->busy = true; c->last_stream = st;
+    if (stats) {
+        PC_HIP(hipEventSynchronize(c->ev[2]));
+        PC_HIP(hipEventElapsedTime(&local.ms_align, c->ev[1], c->ev[2]));
+        local.ms_total = local.ms_align;
+        *stats = local;
+    }
+    return PC_OK;
+}
+
+extern "C" int pc_reduce_dev(pc_ctx* c, int metric, int as_distance, const void* res_dev, void* out_condensed_dev, void* stream) {
+    if (!c || !c->uploaded || !c->plan.valid) { pc_set_error("pc_reduce_dev: pc_plan_dev first"); return PC_ERR_STATE; }
+    if (metric == PC_AAI_PPOS) metric = PC_AAI;
+    if (metric != PC_AAI && metric != PC_PEQ) { pc_set_error("pc_reduce_dev: metric %d", metric); return PC_ERR_ARG; }
+    if (!out_condensed_dev || (!res_dev && c->plan.n_distinct > 0)) { pc_set_error("pc_reduce_dev: NULL argument"); return PC_ERR_ARG; }
+    PC_ON_DEVICE(c);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = stage_reduce(c, metric, as_distance, (const uint2*)res_dev, (double*)out_condensed_dev, st); if (rc != PC_OK) return rc;
+    PC_HIP(hipEventRecord(c->ev[3], st));
+    c->busy = true; c->last_stream = st;
     return PC_OK;
 }
 

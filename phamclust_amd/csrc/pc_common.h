@@ -101,6 +101,8 @@ int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const P
 int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const PcTaskPlan& tp, const uint32_t* task_off_q,
                         PcTask* tasks, int U, hipStream_t st);
 int pc_launch_class_bounds(const unsigned long long* sorted_key, int ntasks, int ncls, uint32_t* cls_begin /*[ncls+1]*/, hipStream_t st);
+int pc_launch_task_slice(const PcTask* sorted, int ntasks, const uint32_t* cls_begin, const uint32_t* slice_begin /*[ncls+1]*/, int rank, int world,
+                         PcTask* out, hipStream_t st);   // every world-th task of each class from `rank`, compacted
 int pc_launch_gather_u32(const uint32_t* src, const int32_t* idx, uint32_t* dst, int n, hipStream_t st);
 int pc_launch_assemble(const double* gathered, int world, int64_t stride, int N, double* out, hipStream_t st);
 int pc_launch_assemble_table(const double* gathered, int64_t stride, int N, const int32_t* t_rank, const int64_t* t_lbase, double* out, hipStream_t st);

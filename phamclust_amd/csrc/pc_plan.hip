@@ -175,6 +175,23 @@ int pc_launch_task_gather(const PcTask* in, const uint32_t* idx, PcTask* out, in
     hipLaunchKernelGGL(k_task_gather, dim3((ntasks + 255) / 256), dim3(256), 0, st, in, idx, out, ntasks);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
+// Every world-th task of each launch class, starting at `rank`, compacted class by class (slice_begin: host-made prefix of
+// the slice's class sizes).  A task's class is its `pad`; its index inside the class is its position in the sorted list minus
+// the class's begin.
+__global__ void k_task_slice(const PcTask* __restrict__ sorted, int ntasks, const uint32_t* __restrict__ cls_begin,
+                             const uint32_t* __restrict__ slice_begin, int rank, int world, PcTask* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntasks) return;
+    const PcTask t = sorted[i];
+    const uint32_t cls = (uint32_t)t.pad, j = (uint32_t)i - cls_begin[cls];
+    if (j % (uint32_t)world == (uint32_t)rank) out[slice_begin[cls] + j / (uint32_t)world] = t;
+}
+int pc_launch_task_slice(const PcTask* sorted, int ntasks, const uint32_t* cls_begin, const uint32_t* slice_begin, int rank, int world,
+                         PcTask* out, hipStream_t st) {
+    if (ntasks <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_task_slice, dim3((ntasks + 255) / 256), dim3(256), 0, st, sorted, ntasks, cls_begin, slice_begin, rank, world, out);
+    return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
 int pc_launch_class_bounds(const unsigned long long* sorted_key, int ntasks, int ncls, uint32_t* cls_begin, hipStream_t st) {
     hipLaunchKernelGGL(k_class_bounds, dim3((ncls + 1 + 63) / 64), dim3(64), 0, st, sorted_key, ntasks, ncls, cls_begin);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;

@@ -69,7 +69,48 @@ def assemble_condensed_host(gathered, n_genomes, world):
     return out
 
 
-def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True):
+def dist_mode():
+    """How an aai / peq fill is spread over the ranks: "pairs" (default; each rank fills the genome pairs of its target
+    genomes, one gather of matrix shards) or "alignments" (PHAMCLUST_DIST_MODE=alignments; every rank plans the whole
+    fill and aligns a slice of the distinct alignments, one reduce of their results, the root builds the matrix:
+    duplicates are merged across the whole job, which is what pays on collections full of identical proteins)."""
+    mode = os.environ.get("PHAMCLUST_DIST_MODE", "pairs")
+    if mode not in ("pairs", "alignments"):
+        raise ValueError(f"PHAMCLUST_DIST_MODE={mode!r}: expected 'pairs' or 'alignments'")
+    return mode
+
+
+def fill_distributed_alignments(ctx, metric, as_distance=True, group=None):
+    """aai / peq over the job's ranks by slicing the ALIGNMENTS (see dist_mode).  Same contract as fill_distributed:
+    (condensed f64 CUDA tensor on rank 0 | None elsewhere, stats of this rank's plan + slice)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    root = dist.get_global_rank(group, 0) if group is not None else 0
+    ctx.set_shard(0, 1)
+    device = torch.device("cuda", ctx.device_id)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    plan = ctx.plan_dev(metric, stream)
+    n = int(plan["n_distinct_alignments"])
+    res = torch.empty(max(n, 1), dtype=torch.int64, device=device)       # (n_ident, aln_len) per distinct alignment
+    stats = ctx.align_slice_dev(rank, world, res.data_ptr(), stream)
+    stats["ms_plan"] = plan["ms_plan"]
+    if world > 1:
+        if dist.get_backend(group) == "gloo":                             # rehearsal transport: staged through host memory
+            host = res.cpu()
+            dist.reduce(host, dst=root, op=dist.ReduceOp.SUM, group=group)
+            if rank == 0:
+                res.copy_(host)
+        else:
+            dist.reduce(res, dst=root, op=dist.ReduceOp.SUM, group=group)  # exactly one rank holds a non-zero entry
+    if rank != 0:
+        return None, stats
+    out = torch.empty(max(ctx.n_pairs, 1), dtype=torch.float64, device=device)
+    ctx.reduce_dev(metric, as_distance, res.data_ptr(), out.data_ptr(), stream)
+    return out[:ctx.n_pairs], stats
+
+
+def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True, mode=None):
     """Sharded fill + the single gather.  ``torch.distributed`` must be initialised (backend
     "nccl" = RCCL) and ``ctx`` must hold the same uploaded genomes on every rank.
     ``balanced`` (default): target genomes are dealt by measured alignment work (``pc_set_shard_balanced``: one
@@ -77,6 +118,8 @@ def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True):
     above describe.  Returns (condensed f64 CUDA tensor on rank 0 | None elsewhere, stats of this rank)."""
     import torch
     import torch.distributed as dist
+    if (mode or dist_mode()) == "alignments" and metric in ("aai", "peq", "aai_ppos"):
+        return fill_distributed_alignments(ctx, metric, as_distance, group)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     root = dist.get_global_rank(group, 0) if group is not None else 0      # dist.gather's dst is a GLOBAL rank
     ctx.set_shard(rank, world, balanced=balanced and world > 1)

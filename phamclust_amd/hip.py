@@ -43,7 +43,8 @@ class PcStats(ctypes.Structure):
 
 EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
-           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs"]
+           "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs",
+           "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev"]
 
 _lib = None
 
@@ -85,6 +86,9 @@ def load():
     L.pc_fill_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
     L.pc_fill_shard_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
     L.pc_assemble_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+    L.pc_plan_dev.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(PcStats)]
+    L.pc_align_slice_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.POINTER(PcStats)]
+    L.pc_reduce_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
     L.pc_align_pairs.argtypes = [vp, _i32p, _i32p, ctypes.c_int64, ctypes.c_int, _i32p, _i32p]
     L.pc_round6_probe.argtypes = [vp, _f64p, _f64p, ctypes.c_int64]
     L.pc_last_align_ms.argtypes = [vp]
@@ -214,6 +218,24 @@ class Context:
     def assemble_dev(self, gathered_ptr, world, out_ptr, stream=None):
         self._check(self._lib.pc_assemble_dev(self._h, ctypes.c_void_p(gathered_ptr), int(world),
                                               ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream or 0)))
+
+    # -- alignment-sliced multi-GPU route (aai / peq): plan everywhere, align a slice, sum to the root, reduce there
+    def plan_dev(self, metric, stream=None):
+        """Plan the whole (unsharded) aai / peq fill; stats["n_distinct_alignments"] is the length of the result array."""
+        stats = PcStats()
+        self._check(self._lib.pc_plan_dev(self._h, METRIC_IDS[metric], ctypes.c_void_p(stream or 0), ctypes.byref(stats)))
+        return stats.as_dict()
+
+    def align_slice_dev(self, slice_rank, slice_world, res_ptr, stream=None, want_stats=True):
+        """Align every slice_world-th task of each launch class from slice_rank; 8 bytes per distinct alignment at res_ptr."""
+        stats = PcStats()
+        self._check(self._lib.pc_align_slice_dev(self._h, int(slice_rank), int(slice_world), ctypes.c_void_p(res_ptr),
+                                                 ctypes.c_void_p(stream or 0), ctypes.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
+
+    def reduce_dev(self, metric, as_distance, res_ptr, out_ptr, stream=None):
+        self._check(self._lib.pc_reduce_dev(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.c_void_p(res_ptr),
+                                            ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream or 0)))
 
     # -- test hooks --------------------------------------------------------------
     def align_pairs(self, a_gene, b_gene, variant=0):

@@ -840,6 +840,87 @@ def test_bench_two_ranks_rehearsal(native_built):
     assert d["verified"]["bit_exact"] is True and d["roofline"]["n_alignments"] > 0
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+@pytest.mark.parametrize("redundant", [False, True])
+def test_alignment_sliced_route_single_gpu(gpu_ctx, native_built, world, redundant):
+    """The alignment-sliced multi-GPU route, all its ranks run back to back on one GPU: plan, every rank's slice into its
+    own result array, the arrays summed as 64-bit integers (the reduce), the root's reduce stage == the unsharded fill.
+    Slices are disjoint, together they hold every distinct alignment, and their DP work is balanced.  `redundant`:
+    many byte-identical proteins, so slots alias distinct alignments across what would be different ranks' pairs."""
+    import dataclasses
+    import torch
+    from phamclust_amd.synth import synth_packed
+    pk = synth_packed(160, 900, seed=13)
+    if redundant:                                  # overwrite 60 % of the genes with their (cluster, pham) group's first sequence
+        G = pk.n_genes
+        genome_of = np.repeat(np.arange(pk.n_genomes, dtype=np.int64), np.diff(pk.gene_off))
+        group = (genome_of // 40) * (pk.n_phams + 1) + pk.gene_pham
+        ug, first = np.unique(group, return_index=True)
+        canon = first[np.searchsorted(ug, group)]
+        src = np.where(np.random.default_rng(7).random(G) < 0.6, canon, np.arange(G))
+        lens = np.diff(pk.seq_off)[src]
+        seq_off = np.zeros(G + 1, dtype=np.int64); np.cumsum(lens, out=seq_off[1:])
+        idx = np.repeat(pk.seq_off[:-1][src] - seq_off[:-1], lens) + np.arange(seq_off[-1])
+        tlen = np.zeros(pk.n_genomes, dtype=np.int64); np.add.at(tlen, genome_of, lens)
+        pk = dataclasses.replace(pk, seq_off=seq_off, residues=np.ascontiguousarray(pk.residues[idx]), tlen=tlen).validate()
+    gpu_ctx.upload(pk)
+    stream = torch.cuda.current_stream().cuda_stream
+    for metric in ("peq", "aai"):
+        want = torch.empty(pk.n_pairs, dtype=torch.float64, device="cuda")
+        st_full = gpu_ctx.fill_dev(metric, True, want.data_ptr(), stream)
+        plan = gpu_ctx.plan_dev(metric, stream)
+        n = plan["n_distinct_alignments"]
+        assert n == st_full["n_distinct_alignments"] and plan["n_alignments"] == st_full["n_alignments"]
+        if redundant:
+            assert n < 0.7 * plan["n_alignments"]
+        parts = []
+        for r in range(world):
+            res = torch.full((max(n, 1),), -1, dtype=torch.int64, device="cuda")
+            gpu_ctx.align_slice_dev(r, world, res.data_ptr(), stream)
+            parts.append(res)
+        torch.cuda.synchronize()
+        stack = torch.stack(parts)[:, :n]
+        assert int((stack != 0).sum(dim=0).max()) <= 1                      # no alignment computed by two ranks ...
+        total = stack.sum(dim=0)
+        assert int((total != 0).sum()) == n                                 # ... and every one by some rank (aln_len >= 1)
+        if world > 1:
+            per_rank = (stack != 0).sum(dim=1).double()
+            assert float(per_rank.max() / per_rank.mean()) < 1.25
+        out = torch.empty(pk.n_pairs, dtype=torch.float64, device="cuda")
+        full = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda"); full[:n] = total
+        gpu_ctx.reduce_dev(metric, True, full.data_ptr(), out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), metric
+    gpu_ctx.set_shard(1, 2)                                                    # a plan belongs to the shard it was made for
+    with pytest.raises(Exception):
+        gpu_ctx.align_slice_dev(0, 1, parts[0].data_ptr(), stream)
+    gpu_ctx.set_shard(0, 1)
+
+
+@pytest.mark.parametrize("mode", ["alignments"])
+def test_bench_two_ranks_rehearsal_alignment_slices(native_built, mode):
+    """bench.py with 2 ranks sharing this box's GPU (gloo transport) on the alignment-sliced route
+    (PHAMCLUST_DIST_MODE=alignments): plan on both ranks, a slice each, one reduce of the results, matrix on rank 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PC_BENCH_BACKEND="gloo", PHAMCLUST_DIST_MODE=mode)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--genomes", "301", "--steps", "2",
+                           "--warmup", "1", "--verify-pairs", "3000"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "alignments sliced" in d["config"]["parallelism"]
+    assert d["verified"]["bit_exact"] is True and d["roofline"]["n_alignments"] > 0
+    assert d["roofline"]["n_distinct_alignments"] <= d["roofline"]["n_alignments"]
+
+
 def test_graft_entry_smoke(native_built):
     """The driver's smoke(): all six metrics on a small synthetic set against the oracle."""
     import importlib

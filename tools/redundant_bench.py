@@ -18,6 +18,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("-n", type=int, default=5000)
 ap.add_argument("--rho", default="0,0.3,0.6,0.9")
 ap.add_argument("--check", type=int, default=3000)
+ap.add_argument("--world", type=int, default=0, help="also run the shard fills of a WORLD-rank job back to back (cost-balanced deal): "
+                "what merging duplicates per rank only costs against the unsharded fill")
 a = ap.parse_args()
 build.build_all()
 base = synth_packed(a.n, 5000)
@@ -53,3 +55,31 @@ for rho in map(float, a.rho.split(",")):
         want = O.pairs(pk, "peq", lo, hi, as_distance=True)
         line += f" | {lo.size} random pairs vs oracle: {'equal' if np.array_equal(out[lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)], want) else 'MISMATCH'}"
     print(line, flush=True)
+    if a.world > 1:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+        ms, distinct, cells = [], 0, 0.0
+        for r in range(a.world):
+            ctx.set_shard(r, a.world, balanced=True)
+            buf = torch.empty(ctx.shard_stride(), dtype=torch.float64, device="cuda")
+            ctx.fill_shard_dev("peq", True, buf.data_ptr(), stream)
+            s_ = ctx.fill_shard_dev("peq", True, buf.data_ptr(), stream); torch.cuda.synchronize()
+            ms.append(s_["ms_total"]); distinct += s_["n_distinct_alignments"]; cells += s_["n_distinct_cells"]
+        ctx.set_shard(0, 1)
+        # the alignment-sliced route: every rank plans the whole fill, aligns its slice; the root reduces after one collective
+        plan = ctx.plan_dev("peq", stream); plan = ctx.plan_dev("peq", stream)
+        n = plan["n_distinct_alignments"]
+        res = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda"); acc = torch.zeros_like(res)
+        sl = []
+        for r in range(a.world):
+            ctx.align_slice_dev(r, a.world, res.data_ptr(), stream)
+            s_ = ctx.align_slice_dev(r, a.world, res.data_ptr(), stream); torch.cuda.synchronize()
+            sl.append(s_["ms_align"]); acc += res
+        outm = torch.empty(pk.n_pairs, dtype=torch.float64, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ctx.reduce_dev("peq", True, acc.data_ptr(), outm.data_ptr(), stream); e1.record(); torch.cuda.synchronize()
+        same = bool(np.array_equal(outm.cpu().numpy(), out))
+        print(f"         {a.world} ranks, alignments sliced: plan {plan['ms_plan']:.1f} ms (every rank) + slowest slice {max(sl):.1f} ms (mean {sum(sl) / len(sl):.1f}) "
+              f"+ reduce of {n * 8 / 1e6:.0f} MB of results + matrix on the root {e0.elapsed_time(e1):.1f} ms; == unsharded fill: {same}", flush=True)
+        print(f"         {a.world} ranks: slowest {max(ms):.1f} ms, sum {sum(ms):.1f} ms ({sum(ms) / st['ms_total']:.2f} x the unsharded fill); alignments computed over all ranks "
+              f"{distinct} = {distinct / max(st['n_distinct_alignments'], 1):.2f} x the unsharded count", flush=True)
