@@ -177,3 +177,15 @@ def test_balanced_deal_mirror_properties():
         assert stride == max(fill) and sum(fill) == n * (n - 1) // 2
     t_rank, _, _ = D.balanced_deal(np.array([5, 5, 5, 5], dtype=np.uint64), 2, pair_floor=0)
     assert t_rank.tolist() == [0, 1, 0, 1]                  # ties: lower index first, lowest rank first
+
+
+def test_dist_mode_switch(monkeypatch):
+    """PHAMCLUST_DIST_MODE picks how an aai / peq fill is split over the ranks; anything else is refused."""
+    from phamclust_amd import distributed as D
+    monkeypatch.delenv("PHAMCLUST_DIST_MODE", raising=False)
+    assert D.dist_mode() == "pairs"
+    monkeypatch.setenv("PHAMCLUST_DIST_MODE", "alignments")
+    assert D.dist_mode() == "alignments"
+    monkeypatch.setenv("PHAMCLUST_DIST_MODE", "rows")
+    with pytest.raises(ValueError):
+        D.dist_mode()
