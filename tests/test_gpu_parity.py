@@ -406,7 +406,7 @@ def test_long_and_ragged_sequences(gpu_ctx, native_built):
     g = pk.n_genes
     a, b = np.meshgrid(np.arange(g, dtype=np.int32), np.arange(g, dtype=np.int32))
     a, b = a.ravel(), b.ravel()
-    keep = rng.random(a.shape[0]) < 0.15
+    keep = rng.random(a.shape[0]) < 0.07
     a, b = a[keep], b[keep]
     ident, diag = gpu_ctx.align_pairs(a, b)
     _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
@@ -736,7 +736,7 @@ def test_unsynchronised_fill_survives_reupload(gpu_ctx, native_built):
     import torch
     from phamclust_amd.synth import synth_packed
     O = _oracle()
-    a_pk, b_pk = synth_packed(260, 900, seed=41), synth_packed(110, 400, seed=42)
+    a_pk, b_pk = synth_packed(170, 900, seed=41), synth_packed(90, 400, seed=42)
     want_a, want_b = O.fill(a_pk, "peq", as_distance=True), O.fill(b_pk, "peq", as_distance=True)
     side = torch.cuda.Stream()
     for _ in range(3):
