@@ -986,6 +986,14 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
             i = j;
         }
         while (cur_cls < ncls_all) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
+        // Longest tasks first inside a class, as pc_fill's plan orders them.  Workgroups go to the 8 XCDs round-robin by block
+        // index, so a list that alternates full tasks and left-overs (every bucket cut the same way) puts all the full ones on
+        // half of the XCDs: measured 2x the time on uniform test data.
+        for (int cl = 0; cl < ncls_all; ++cl)
+            std::stable_sort(tasks.begin() + cls_task_begin[cl], tasks.begin() + cls_task_begin[cl + 1], [&](const PcTask& x, const PcTask& y) {
+                const int64_t wx = (int64_t)(x.end - x.begin) * c->h_gene_len[x.gene], wy = (int64_t)(y.end - y.begin) * c->h_gene_len[y.gene];
+                return wx > wy;
+            });
     }
     DevBuf d_sums, d_ident, d_diag;
     hipStream_t st = c->stream;

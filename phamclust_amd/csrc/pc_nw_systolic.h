@@ -334,9 +334,9 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
         bc[q] = v;
     }
     __syncthreads();                                 // score table visible
-    if (seg == 0) {                                  // each wave's segment-0 lanes write a quarter of the profile rows
-#pragma unroll 1
-        for (int r = wv; r < ROWS; r += NWV) {
+    if (in_seg) {                                    // every segment of every wave writes its share of the profile rows (all segments hold
+#pragma unroll 1                                     // the same column codes): 25 rows over NWV * nseg workers of G lanes
+        for (int r = wv * nseg + seg; r < ROWS; r += NS) {
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
                 uint32_t v = 0;
