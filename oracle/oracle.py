@@ -38,8 +38,8 @@ class _Packed(ctypes.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
-    src = os.path.join(_HERE, "pc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, name)) for name in ("pc_oracle.c", "pc_cooptimal.c", "Makefile"))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpc_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -69,6 +69,14 @@ def lib():
         L.pco_set_tie_rule.argtypes = [ctypes.c_int]
         L.pco_set_tie_rule.restype = None
         L.pco_tie_sensitivity.argtypes = [ctypes.POINTER(_Packed), _i32p, _i32p, ctypes.c_int64, _f64p, _f64p, _i64p, ctypes.c_int]
+        L.pco_set_gap.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.pco_set_gap.restype = None
+        L.pco_set_compat.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.pco_set_compat.restype = None
+        L.pcc_cooptimal.argtypes = [_u8p, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_int, _i32p, _u64p, _i32p]
+        L.pcc_batch.argtypes = [_u8p, _i64p, _i32p, _i32p, ctypes.c_int64, ctypes.c_int, _i32p, _u64p, _i32p, ctypes.c_int]
+        L.pcc_enumerate.argtypes = [ctypes.POINTER(_Packed), _i32p, _i32p, ctypes.c_int64, _i32p, _i32p, _i64p, ctypes.c_int64]
+        L.pcc_enumerate.restype = ctypes.c_int64
         _lib = L
     return _lib
 
@@ -224,6 +232,62 @@ def tie_sensitivity(packed, s_idx, t_idx, nthreads=0):
     lib().pco_tie_sensitivity(ctypes.byref(_struct(packed)), _ptr(s_idx, _i32p), _ptr(t_idx, _i32p), n, _ptr(aai, _f64p),
                               _ptr(peq, _f64p), _ptr(counters, _i64p), nthreads)
     return aai, peq, counters
+
+
+# ---------------------------------------------------------------------------
+# Co-optimal certificate (pc_cooptimal.c): an independent three-state DP that counts ALL optimal alignments of a
+# sequence pair and the range of (n_ident, n_diag) over them.  min == max for both => the statistics are the same for
+# every optimal alignment, so any correct Needleman-Wunsch (parasail included) must report them.
+# ---------------------------------------------------------------------------
+COUNT_SATURATED = (1 << 64) - 1
+
+
+def cooptimal(seq_a, seq_b, ppos=False):
+    """-> (score, n_optimal_alignments, (id_lo, id_hi), (dg_lo, dg_hi))"""
+    a, b = _as_bytes(seq_a), _as_bytes(seq_b)
+    sc, cnt = ctypes.c_int32(), ctypes.c_uint64()
+    rng = (ctypes.c_int32 * 4)()
+    ab = (ctypes.c_uint8 * len(a)).from_buffer_copy(a)
+    bb = (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+    if lib().pcc_cooptimal(ab, len(a), bb, len(b), int(bool(ppos)), ctypes.byref(sc), ctypes.byref(cnt), rng) != 0:
+        raise ValueError("pcc_cooptimal failed (empty sequence?)")
+    return sc.value, cnt.value, (rng[0], rng[1]), (rng[2], rng[3])
+
+
+def cooptimal_batch(residues, seq_off, a_idx, b_idx, ppos=False, nthreads=0):
+    """(score int32[n], count uint64[n], range int32[n,4] = id_lo, id_hi, dg_lo, dg_hi) for gene-index pairs."""
+    a_idx = np.ascontiguousarray(a_idx, dtype=np.int32)
+    b_idx = np.ascontiguousarray(b_idx, dtype=np.int32)
+    n = a_idx.shape[0]
+    sc, cnt, rng = np.zeros(n, np.int32), np.zeros(n, np.uint64), np.zeros((n, 4), np.int32)
+    if lib().pcc_batch(_ptr(residues, _u8p), _ptr(seq_off, _i64p), _ptr(a_idx, _i32p), _ptr(b_idx, _i32p), n, int(bool(ppos)),
+                       _ptr(sc, _i32p), _ptr(cnt, _u64p), _ptr(rng, _i32p), nthreads) != 0:
+        raise ValueError("pcc_batch failed")
+    return sc, cnt, rng
+
+
+def enumerate_alignments(packed, s_idx, t_idx):
+    """The alignments the reference runs for the listed genome pairs, in its loop order (metrics.py:203-214).
+    -> (a_gene int32[A] = seq_a / rows, b_gene int32[A] = seq_b / columns, pair_of int64[A] = index into the pair list)."""
+    s_idx = np.ascontiguousarray(s_idx, dtype=np.int32)
+    t_idx = np.ascontiguousarray(t_idx, dtype=np.int32)
+    st = _struct(packed)
+    n = s_idx.shape[0]
+    total = lib().pcc_enumerate(ctypes.byref(st), _ptr(s_idx, _i32p), _ptr(t_idx, _i32p), n, None, None, None, 0)
+    a, b, q = np.zeros(total, np.int32), np.zeros(total, np.int32), np.zeros(total, np.int64)
+    if total:
+        lib().pcc_enumerate(ctypes.byref(st), _ptr(s_idx, _i32p), _ptr(t_idx, _i32p), n, _ptr(a, _i32p), _ptr(b, _i32p), _ptr(q, _i64p), total)
+    return a, b, q
+
+
+def set_gap(open_=11, extend=1):
+    """Gap costs of every aligner entry point (process-wide); the reference's are 11 / 1 (metrics.py:160)."""
+    lib().pco_set_gap(int(open_), int(extend))
+
+
+def set_compat(case_sensitive=False, unknown_row=23, lower_unknown=False):
+    """Recalled parasail behaviours as switches; defaults restore them."""
+    lib().pco_set_compat(int(bool(case_sensitive)), int(unknown_row), int(bool(lower_unknown)))
 
 
 # ---------------------------------------------------------------------------

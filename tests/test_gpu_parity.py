@@ -928,3 +928,39 @@ def test_graft_entry_smoke(native_built):
     from conftest import REPO
     sys.path.insert(0, REPO)
     importlib.import_module("__graft_entry__").smoke()
+
+
+@pytest.mark.parametrize("dataset", ["small_input", "synth2000"])
+def test_certified_alignments_equal_the_unique_statistics(gpu_ctx, native_built, small_packed, dataset):
+    """Reference-independent pin of the aligner at real lengths (metrics.py:160-175, 216-217).  oracle/pc_cooptimal.c
+    counts EVERY optimal global alignment of a sequence pair and the range of (n_ident, n_diag) over them, with a DP that
+    shares nothing with the oracle's aligner and is itself pinned by brute force (tests/test_cooptimal.py).  Where the
+    range is one point any correct Needleman-Wunsch -- parasail included -- must report it: the kernels must, on every
+    such alignment, through the default variant chooser; everywhere else they must stay inside the range."""
+    from phamclust_amd.synth import synth_packed
+    from phamclust_amd.csrc_info import variant_width_of_length
+    O = _oracle()
+    if dataset == "small_input":
+        packed = small_packed
+        iu = np.triu_indices(packed.n_genomes, 1)
+        s_idx, t_idx = iu[0], iu[1]
+    else:
+        packed = synth_packed(2000, 5000)
+        rng = np.random.default_rng(20241218)                   # head of the sample behind tests/golden/unique_optimum.json
+        s = rng.integers(0, packed.n_genomes, 100000)
+        t = rng.integers(0, packed.n_genomes, 100000)
+        keep = s != t
+        s_idx, t_idx = np.minimum(s, t)[keep][:4000], np.maximum(s, t)[keep][:4000]
+    a, b, _ = O.enumerate_alignments(packed, s_idx, t_idx)
+    _, count, rng4 = O.cooptimal_batch(packed.residues, packed.seq_off, a, b)
+    cert = (rng4[:, 0] == rng4[:, 1]) & (rng4[:, 2] == rng4[:, 3])
+    gpu_ctx.upload(packed)
+    ident, diag = gpu_ctx.align_pairs(a, b, variant=0)
+    assert cert.sum() > 0.8 * a.shape[0] > 1000
+    assert np.array_equal(ident[cert], rng4[cert, 0]) and np.array_equal(diag[cert], rng4[cert, 2])
+    assert ((rng4[:, 0] <= ident) & (ident <= rng4[:, 1]) & (rng4[:, 2] <= diag) & (diag <= rng4[:, 3])).all()
+    assert (count[~cert] > 1).all()
+    # the certified set runs through many widths of the default chooser
+    lens = (packed.seq_off[1:] - packed.seq_off[:-1])[b[cert]]
+    widths = {variant_width_of_length(int(x)) for x in np.unique(lens)}
+    assert len(widths) >= (8 if dataset == "synth2000" else 4), sorted(widths)

@@ -64,6 +64,47 @@ def summarise(aai, peq, counters):
     return rows
 
 
+ALPHABET = b"ARNDCQEGHILKMFPSTWYVBZX*"
+
+
+def conventions(O, packed, s_idx, t_idx):
+    """The other recalled parasail behaviours, each flipped alone against the defaults: how many
+    residues of the data set it can touch at all, and what it moves.  Similarities rounded to 6 places, as above."""
+    res = np.asarray(packed.residues)
+    upper = np.zeros(256, bool); upper[list(ALPHABET)] = True
+    lower = np.zeros(256, bool); lower[[c + 32 for c in ALPHABET if 65 <= c <= 90]] = True
+    n_lower = int(lower[res].sum())
+    n_other = int((~upper[res] & ~lower[res]).sum())
+    base = {m: O.pairs(packed, m, s_idx, t_idx, as_distance=False) for m in ("aai", "peq")}
+    out = {"residues": int(res.size), "lower_case_residues": n_lower, "residues_outside_the_24_letters": n_other, "switches": []}
+
+    def measure(name, touches, setup, teardown, what):
+        row = {"switch": name, "what": what, "residues_it_can_touch": touches}
+        if touches == 0:
+            row.update({"aai_moved_gt_1e-6_frac": 0.0, "peq_moved_gt_1e-6_frac": 0.0, "max_abs_d_aai": 0.0, "max_abs_d_peq": 0.0,
+                        "note": "no residue of this data set is affected: exposure is zero by construction"})
+        else:
+            setup()
+            try:
+                for m in ("aai", "peq"):
+                    d = np.abs(O.pairs(packed, m, s_idx, t_idx, as_distance=False) - base[m])
+                    row[f"{m}_moved_gt_1e-6_frac"] = float((d > 1e-6).mean())
+                    row[f"max_abs_d_{m}"] = float(d.max())
+            finally:
+                teardown()
+        out["switches"].append(row)
+
+    measure("case_sensitive_identity", n_lower, lambda: O.set_compat(case_sensitive=True), O.set_compat,
+            "item 6: '|' only for byte-equal residues (default: case-insensitive)")
+    measure("lower_case_outside_alphabet", n_lower, lambda: O.set_compat(lower_unknown=True), O.set_compat,
+            "item 7: lower-case letters score as an unknown byte (default: like upper case)")
+    measure("unknown_byte_scores_as_X", n_other, lambda: O.set_compat(unknown_row=22), O.set_compat,
+            "item 7: a byte outside the alphabet takes the X row (default: the * row)")
+    measure("gap_of_k_costs_open_plus_k_extend", int(res.size), lambda: O.set_gap(12, 1), O.set_gap,
+            "item 2: the other affine convention (BLAST's), i.e. the same recurrence with open = 12 (default: 11 + (k-1))")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=50000, help="genome pairs sampled from synth(2000,5000)")
@@ -88,7 +129,8 @@ def main():
     t0 = time.time()
     aai, peq, counters = O.tie_sensitivity(small, iu[0], iu[1])
     report["datasets"].append({"name": "tests/golden/small_input.tsv", "genomes": small.n_genomes, "pairs": "all",
-                               "seconds": round(time.time() - t0, 1), "rules": summarise(aai, peq, counters)})
+                               "seconds": round(time.time() - t0, 1), "rules": summarise(aai, peq, counters),
+                               "other_recalled_conventions": conventions(O, small, iu[0], iu[1])})
     print(f"small_input: {time.time() - t0:.1f} s", flush=True)
 
     big = synth_packed(2000, 5000)
@@ -101,7 +143,8 @@ def main():
     aai, peq, counters = O.tie_sensitivity(big, lo, hi)
     report["datasets"].append({"name": "synth(2000,5000)", "genomes": big.n_genomes,
                                "pairs": f"{lo.size} random pairs, numpy default_rng(20241218)",
-                               "seconds": round(time.time() - t0, 1), "rules": summarise(aai, peq, counters)})
+                               "seconds": round(time.time() - t0, 1), "rules": summarise(aai, peq, counters),
+                               "other_recalled_conventions": conventions(O, big, lo, hi)})
     print(f"synth(2000,5000) sample: {time.time() - t0:.1f} s", flush=True)
 
     worst = {}
