@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PC_VERSION 130   /* 0.2.0: tie-rule table (pc_set_tie_rule), pinned-host fills */
+#define PC_VERSION 140   /* 0.3.0: two-part upload, memory-bounded (chunked) aai / peq fills */
 
 typedef enum {
     PC_OK = 0,
@@ -75,7 +75,7 @@ typedef struct {
     int64_t n_tasks;            /* wave tasks launched by the alignment kernels             */
     int64_t n_residue_bytes;    /* sum of (la+lb) over alignments: algorithmic input bytes  */
     int32_t n_align_launches;   /* alignment kernel launches                                */
-    int32_t reserved;
+    int32_t n_chunks;           /* plan -> align -> reduce passes the fill took (1 unless the plan exceeded the budget) */
     float ms_total;             /* whole call, device side                                  */
     float ms_plan;              /* pair walk: counts, scans, bucketing, task build          */
     float ms_align;             /* alignment kernels only (the dominant kernels)            */
@@ -94,6 +94,17 @@ void pc_ctx_destroy(pc_ctx* ctx);
 /* Copy the packed genomes to HBM and build the device-side indices (rank table, gene
  * table, encoded residues).  Replaces any previous upload. */
 int pc_upload(pc_ctx* ctx, const pc_packed* genomes);
+
+/* The same in two parts.  gcs / jc / pocp / af read pham sets, gene counts and translation LENGTHS only
+ * (metrics.py:26-157), and encoding, de-duplicating and ranking the residues is ~90 % of pc_upload's time:
+ *   pc_upload_sets      bitmap, rank table, (genome, pham) entries, per-genome scalars -- enough for the four set metrics
+ *                       and for pc_set_shard*; replaces any previous upload;
+ *   pc_upload_residues  what aai / peq and pc_align_pairs need on top; `genomes` must be the packed genomes
+ *                       pc_upload_sets was given (checked by size; the caller keeps them alive in between).  A no-op
+ *                       when the residues are already there.
+ * aai / peq fills before pc_upload_residues return PC_ERR_STATE. */
+int pc_upload_sets(pc_ctx* ctx, const pc_packed* genomes);
+int pc_upload_residues(pc_ctx* ctx, const pc_packed* genomes);
 
 /*
  * Static shard of the upper-triangular pair list: rank r of `world` owns the pairs
@@ -124,6 +135,21 @@ int pc_target_costs(const pc_ctx* ctx, uint64_t* cost);
  * the reference returns them; the diagonal is not produced (matrix.py:467-468 presets it).
  */
 int pc_fill(pc_ctx* ctx, int metric, int as_distance, double* out_condensed, pc_stats* stats);
+
+/*
+ * Memory-bounded batching of aai / peq fills (the reference bounds its in-flight work the same way: ~10,000 pairs per
+ * CPU per batch, matrix.py:474-493).  The plan of a fill costs ~56 bytes of HBM per alignment; when that exceeds the
+ * budget -- bytes, 0 = automatic: half of the HBM free at the time; environment PC_PLAN_BYTES at context creation -- or
+ * the 2^31-2 alignments one plan can index, every fill entry point runs plan -> align -> reduce over successive ranges of
+ * its target genomes (pc_stats.n_chunks passes) and produces the same values bit for bit.  A device allocation that fails
+ * inside a fill is answered by halving the chunk, not by an error.  Only pc_plan_dev (the alignment-sliced route, which
+ * keeps the whole plan resident) still refuses more than 2^31-2 alignments.
+ */
+int pc_set_plan_budget(pc_ctx* ctx, int64_t bytes);
+/* The chunking rule itself, host arithmetic only (no GPU; exported for tests): cut count[0..n) into consecutive ranges
+ * whose sums stay <= max_per_chunk (an element above it gets a range of its own).  chunk_begin receives the range starts
+ * followed by n (at most cap entries are written); returns the number of ranges. */
+int pc_chunk_plan(const uint64_t* count, int n, uint64_t max_per_chunk, int32_t* chunk_begin, int cap);
 
 /* Same values, delivered in page-locked host memory owned by the context (grow-only, pinned once): *out_host points to
  * f64[N(N-1)/2] and stays valid until the next fill or upload on this context, or its destruction.  This is the call
@@ -186,6 +212,9 @@ int pc_align_pairs(pc_ctx* ctx, const int32_t* a_gene, const int32_t* b_gene, in
 #define PC_NUM_TIE_RULES 8
 int pc_set_tie_rule(pc_ctx* ctx, int rule);
 int pc_get_tie_rule(const pc_ctx* ctx);
+
+/* Test hook: columns per lane of the systolic variant the chooser picks for a column gene of lb residues; 0 = general kernel. */
+int pc_variant_width(int lb);
 
 /* Test / tuning hook: HIP-event milliseconds of the alignment kernels of the last pc_align_pairs call. */
 float pc_last_align_ms(const pc_ctx* ctx);

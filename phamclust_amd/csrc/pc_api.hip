@@ -35,14 +35,27 @@ extern "C" int pc_version(void) { return PC_VERSION; }
 
 namespace {
 
+// internal status: a device allocation failed.  A chunked fill answers it with smaller chunks; at the C-ABI it is PC_ERR_HIP.
+constexpr int PC_ERR_NOMEM_INTERNAL = -100;
+// test hook (PC_FAKE_OOM_ABOVE=bytes): device allocations above that size made while a fill is planning fail, as if HBM
+// were that small
+static thread_local bool g_planning = false;
+static size_t fake_oom_limit() {
+    static const size_t v = [] { const char* e = getenv("PC_FAKE_OOM_ABOVE"); return e ? (size_t)atoll(e) : (size_t)0; }();
+    return g_planning ? v : 0;
+}
+struct PlanningScope { PlanningScope() { g_planning = true; } ~PlanningScope() { g_planning = false; } };
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return PC_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { pc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return PC_ERR_HIP; }
+        hipError_t e = (fake_oom_limit() && want > fake_oom_limit()) ? hipErrorOutOfMemory : hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            pc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; (void)hipGetLastError();
+            return e == hipErrorOutOfMemory ? PC_ERR_NOMEM_INTERNAL : PC_ERR_HIP;
+        }
         cap = want; return PC_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -59,15 +72,17 @@ template <class F> void parallel_chunks(int64_t n, F fn) {
     for (auto& x : th) x.join();
 }
 
+static inline int abi_rc(int rc) { return rc == PC_ERR_NOMEM_INTERNAL ? PC_ERR_HIP : rc; }
+
 static int upload_raw(DevBuf& b, const void* p, size_t bytes) {
-    int rc = b.ensure(std::max<size_t>(bytes, 16));
+    int rc = abi_rc(b.ensure(std::max<size_t>(bytes, 16)));
     if (rc != PC_OK) return rc;
     if (bytes) PC_HIP(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice));
     return PC_OK;
 }
 
 template <class T> int upload_vec(DevBuf& b, const std::vector<T>& v) {
-    int rc = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+    int rc = abi_rc(b.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
     if (rc != PC_OK) return rc;
     if (!v.empty()) PC_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return PC_OK;
@@ -78,7 +93,9 @@ template <class T> int upload_vec(DevBuf& b, const std::vector<T>& v) {
 struct pc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool uploaded = false;
+    bool uploaded = false;                  // part 1 of the upload is on the device (set metrics can run)
+    bool residues_ready = false;            // ... and part 2 (aai / peq, pc_align_pairs can run)
+    int64_t n_residue_bytes_in = 0;         // residue bytes of the packed genomes part 1 saw (part 2 must be given the same)
     PcDev dev{};
     std::vector<int32_t> h_gene_len;
     std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
@@ -95,16 +112,20 @@ struct pc_ctx {
     std::vector<uint64_t> target_cost;      // DP cells per target genome, computed once per upload
     std::vector<int32_t> h_t_rank;          // the deal in force, host copy: owner rank of each target genome ...
     std::vector<int64_t> h_t_lbase;         // ... and where its pairs start inside that rank's shard
+    std::vector<int32_t> h_owned;           // this rank's targets, ascending, and
+    std::vector<int64_t> h_lbase;           // [nown+1] the shard-local index of pair (0, owned[k]) (host copies of shard.owned / lbase)
     // persistent device arrays
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
     DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
-    DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut, b_slice_begin;
+    DevBuf b_tasks, b_tasks_sorted, b_bucket_row, b_bucket_dest, b_res, b_totals, b_plan, b_scratch, b_out, b_lut, b_slice_begin, b_aln_t;
     uint32_t* h_plan = nullptr;             // pinned: [ncls+1] task offsets, then 3 u64 totals
     // what the last alignment plan (stage_plan) left in the work buffers, for the stages that follow it
     struct PlanState {
         bool valid = false; int ppos = 0; int condensed = 1; int64_t A = 0, n_distinct = 0; uint32_t ntasks = 0;
+        int k0 = 0, k1 = 0;                 // the owned targets [k0, k1) the plan covers (a chunk of the shard, or all of it)
+        bool whole = false;                 // ... all of an unsharded context: what the alignment-sliced route needs
         std::vector<uint32_t> tb;           // [ncls+1] task range per launch class in b_tasks_sorted
         pc_stats st;                        // counts of the plan (alignments, cells, tasks, distinct ...)
     } plan;
@@ -116,8 +137,11 @@ struct pc_ctx {
     hipEvent_t aux_ev[kAux + 1] = {};
     int n_streams = kAux + 1;               // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
     int tie_rule = 0;                       // row of the aligner's tie-rule table (pc_set_tie_rule)
-    bool busy = false;                      // ev[3] was recorded on a caller's stream and not waited for yet
+    int64_t lut_key = -1; const double* lut_ptr = nullptr;   // what the gcs / jc epilogue table in b_lut was built for
+    hipEvent_t ev_last = nullptr;           // recorded at the end of every entry point that leaves work on a caller's stream
+    bool busy = false;                      // ev_last was recorded and not waited for yet
     hipStream_t last_stream = nullptr;      // ... on this stream
+    int64_t plan_budget = 0;                // bytes of plan buffers one chunk of an aai / peq fill may use; 0: automatic (pc_set_plan_budget)
 };
 
 #ifndef PC_TIE_RULE_DEFAULT
@@ -141,14 +165,20 @@ struct PcDeviceGuard {
 };
 #define PC_ON_DEVICE(c) PcDeviceGuard pc_guard_((c)->device); if (!pc_guard_.ok) return PC_ERR_HIP
 
-// A fill without stats returns while its kernels still run on the CALLER's stream and still use the context's work
-// buffers and shard tables.  Anything that rewrites those (upload, re-shard, the test hooks, a fill on another
-// stream) first waits for the event the last fill recorded at its end.
-static int wait_last_fill(pc_ctx* c, hipStream_t next_stream, bool same_stream_is_ordered) {
+// A fill (or plan, slice, reduce) without stats returns while its kernels still run on the CALLER's stream and still use
+// the context's work buffers and shard tables.  Every such entry point ends in mark_work(): ONE event, recorded after its
+// last launch.  Anything that rewrites those buffers (upload, re-shard, the test hooks, work on another stream) first
+// waits for it.
+static int wait_last_work(pc_ctx* c, hipStream_t next_stream, bool same_stream_is_ordered) {
     if (!c->busy) return PC_OK;
     if (same_stream_is_ordered && next_stream == c->last_stream) return PC_OK;
-    PC_HIP(hipEventSynchronize(c->ev[3]));
+    PC_HIP(hipEventSynchronize(c->ev_last));
     c->busy = false;
+    return PC_OK;
+}
+static int mark_work(pc_ctx* c, hipStream_t st) {
+    PC_HIP(hipEventRecord(c->ev_last, st));
+    c->busy = true; c->last_stream = st;
     return PC_OK;
 }
 
@@ -165,6 +195,8 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
+    if (const char* env = getenv("PC_PLAN_BYTES")) { const long long v = atoll(env); if (v > 0) c->plan_budget = v; }
     for (int i = 0; i < pc_ctx::kAux && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
     for (int i = 0; i <= pc_ctx::kAux && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
     if (const char* env = getenv("PC_ALIGN_STREAMS")) { int v = atoi(env); if (v >= 1 && v <= pc_ctx::kAux + 1) c->n_streams = v; }
@@ -179,16 +211,17 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
 extern "C" void pc_ctx_destroy(pc_ctx* c) {
     if (!c) return;
     PcDeviceGuard guard(c->device);
-    if (c->busy) (void)hipEventSynchronize(c->ev[3]);
+    if (c->busy && c->ev_last) (void)hipEventSynchronize(c->ev_last);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
                       &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_tasks_sorted, &c->b_bucket_row, &c->b_bucket_dest,
-                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut, &c->b_slice_begin};
+                      &c->b_res, &c->b_totals, &c->b_plan, &c->b_scratch, &c->b_out, &c->b_lut, &c->b_slice_begin, &c->b_aln_t};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     for (int i = 0; i < pc_ctx::kAux; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
     for (int i = 0; i <= pc_ctx::kAux; ++i) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
     if (c->h_plan) (void)hipHostFree(c->h_plan);
@@ -251,15 +284,18 @@ static int apply_shard(pc_ctx* c, int rank, int world) {
     c->rank = rank; c->world = world; c->balanced = false;
     int rc = upload_vec(c->b_owned, owned); if (rc != PC_OK) return rc;
     rc = upload_vec(c->b_lbase, lbase); if (rc != PC_OK) return rc;
+    c->h_owned = owned; c->h_lbase = lbase;
     c->shard.nown = (int32_t)owned.size();
+    c->shard.ident = world == 1 ? 1 : 0;
     c->shard.owned = c->b_owned.as<int32_t>();
     c->shard.lbase = c->b_lbase.as<int64_t>();
     return PC_OK;
 }
 
-extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
-    if (!c || !g) { pc_set_error("pc_upload: NULL argument"); return PC_ERR_ARG; }
-    PC_ON_DEVICE(c);
+// Upload, part 1: everything gcs / jc / pocp / af read -- the bitmap, the rank table, the (genome, pham) entries and the
+// per-genome scalars.  The reference's set metrics never touch a translation beyond its length (metrics.py:26-157), and
+// encoding, hashing and ranking 10^8 residues is 90 % of a full upload.
+static int upload_sets(pc_ctx* c, const pc_packed* g) {
     int rc = PC_OK;
     const int N = g->n_genomes, P = g->n_phams, W = g->words_per_row;
     if (N <= 0 || P < 0 || W != std::max(1, (P + 63) / 64) || g->reserved != 0 || !g->bitmap || !g->nph || !g->ngen || !g->tlen ||
@@ -279,8 +315,8 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         fprintf(stderr, "pc_upload %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    if ((rc = wait_last_fill(c, nullptr, false))) return rc;
-    c->uploaded = false; c->target_cost.clear(); c->plan.valid = false;
+    if ((rc = wait_last_work(c, nullptr, false))) return rc;
+    c->uploaded = false; c->residues_ready = false; c->target_cost.clear(); c->plan.valid = false;
     PC_HIP(hipStreamSynchronize(c->stream));
 
     // ---- host-side indices -------------------------------------------------------
@@ -288,15 +324,12 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
     std::vector<uint64_t> bitmap((size_t)N * Wstride, 0);
     std::vector<uint32_t> rankpre((size_t)N * W);
     std::vector<int32_t> ent_cnt, ent_len, ent_gene, gene_len(G);
-    std::vector<int64_t> gene_off(G);
     ent_cnt.reserve(G); ent_len.reserve(G); ent_gene.reserve(G);
-    int64_t code_bytes = 0;
     int maxlen = 0, minlen = G ? 0x7fffffff : 0;
     for (int k = 0; k < G; ++k) {
         const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
         if (len < 0 || len > 65535) { pc_set_error("pc_upload: gene %d has length %lld (limit 65535)", k, (long long)len); return PC_ERR_LIMIT; }
-        gene_len[k] = (int32_t)len; gene_off[k] = code_bytes;
-        code_bytes += (len + 15) & ~15LL;
+        gene_len[k] = (int32_t)len;
         maxlen = std::max(maxlen, (int)len); minlen = std::min(minlen, (int)len);
     }
     for (int s = 0; s < N; ++s) {
@@ -324,6 +357,57 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
         }
     }
     lap("entries, rank table");
+    std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
+    std::vector<int64_t> tlen(g->tlen, g->tlen + N);
+    if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
+        (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
+        (rc = upload_vec(c->b_nph, nph)) || (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)))
+        return rc;
+    PcDev& d = c->dev;
+    memset(&d, 0, sizeof(d));
+    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)ent_cnt.size();
+    d.bitmap = c->b_bitmap.as<uint64_t>(); d.rankpre = c->b_rankpre.as<uint32_t>();
+    d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
+    d.gene_len = c->b_gene_len.as<int32_t>();
+    d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
+    c->h_gene_len.swap(gene_len);
+    c->max_gene_len = maxlen; c->min_gene_len = minlen;
+    c->max_nph = 0;
+    for (int s2 = 0; s2 < N; ++s2) c->max_nph = std::max(c->max_nph, (int)g->nph[s2]);
+    c->n_residue_bytes_in = g->seq_off[G] - g->seq_off[0];
+    rc = apply_shard(c, 0, 1);
+    if (rc != PC_OK) return rc;
+    lap("device copies (sets)");
+    c->uploaded = true;
+    return PC_OK;
+}
+
+// Upload, part 2: what the aligner needs -- residue codes, the distinct sequences and their ranks, the launch classes.
+// g must be the packed genomes part 1 was given.
+static int upload_residues(pc_ctx* c, const pc_packed* g) {
+    int rc = PC_OK;
+    const int N = g->n_genomes;
+    const int G = c->dev.G;
+    if (N != c->dev.N || g->gene_off[N] != (int64_t)G || g->seq_off[G] - g->seq_off[0] != c->n_residue_bytes_in) {
+        pc_set_error("pc_upload_residues: not the genomes pc_upload_sets was given (N %d/%d, genes %lld/%d)", N, c->dev.N, (long long)g->gene_off[N], G);
+        return PC_ERR_ARG;
+    }
+    static const bool timing = getenv("PC_UPLOAD_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "pc_upload %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
+    if ((rc = wait_last_work(c, nullptr, false))) return rc;
+    c->residues_ready = false; c->plan.valid = false;
+    PC_HIP(hipStreamSynchronize(c->stream));
+    const std::vector<int32_t>& gene_len = c->h_gene_len;
+    const int maxlen = c->max_gene_len;
+    std::vector<int64_t> gene_off(G);
+    int64_t code_bytes = 0;
+    for (int k = 0; k < G; ++k) { gene_off[k] = code_bytes; code_bytes += ((int64_t)gene_len[k] + 15) & ~15LL; }
     // encoded residues (16-byte padded per gene) and a 64-bit hash of each gene's codes, on several host threads
     // (not a std::vector: value-initialising ~10^8 bytes on one thread cost as much as encoding them on sixteen; the worker
     // threads below are the first to touch their part)
@@ -450,40 +534,48 @@ extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
 
     lap("launch classes");
     // ---- device copies ---------------------------------------------------------------
-    std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
-    std::vector<int64_t> tlen(g->tlen, g->tlen + N);
-    if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
-        (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
-        (rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_raw(c->b_codes, codes.get(), codes_size)) || (rc = upload_vec(c->b_nph, nph)) ||
-        (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)) || (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
+    if ((rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_raw(c->b_codes, codes.get(), codes_size)) ||
+        (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
         (rc = upload_vec(c->b_q_class, q_class)) || (rc = upload_vec(c->b_q_nseg, q_nseg)) || (rc = upload_vec(c->b_rem_class, rem_class)) ||
         (rc = c->b_cls_begin.ensure((ncls_all + 1) * 4)))
         return rc;
     c->task_plan.task_rows = c->b_task_rows.as<int32_t>(); c->task_plan.q_class = c->b_q_class.as<uint8_t>();
     c->task_plan.q_nseg = c->b_q_nseg.as<uint8_t>(); c->task_plan.rem_class = c->b_rem_class.as<uint8_t>();
     PcDev& d = c->dev;
-    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)ent_cnt.size();
     d.U = U; d.ubits = ubits; d.gene_q = c->b_gene_q.as<uint32_t>(); d.q_gene = c->b_q_gene.as<int32_t>();
-    d.bitmap = c->b_bitmap.as<uint64_t>(); d.rankpre = c->b_rankpre.as<uint32_t>();
-    d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
-    d.gene_len = c->b_gene_len.as<int32_t>(); d.gene_off = c->b_gene_off.as<int64_t>(); d.codes = c->b_codes.as<uint8_t>();
-    d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
-    c->h_gene_len.swap(gene_len); c->h_gene_odd.swap(godd);
-    c->max_gene_len = maxlen; c->min_gene_len = minlen;
-    c->max_nph = 0;
-    for (int s2 = 0; s2 < N; ++s2) c->max_nph = std::max(c->max_nph, (int)g->nph[s2]);
-    rc = apply_shard(c, 0, 1);
-    if (rc != PC_OK) return rc;
-    lap("device copies");
-    c->uploaded = true;
+    d.gene_off = c->b_gene_off.as<int64_t>(); d.codes = c->b_codes.as<uint8_t>();
+    c->h_gene_odd.swap(godd);
+    lap("device copies (residues)");
+    c->residues_ready = true;
     return PC_OK;
+}
+
+extern "C" int pc_upload_sets(pc_ctx* c, const pc_packed* g) {
+    if (!c || !g) { pc_set_error("pc_upload_sets: NULL argument"); return PC_ERR_ARG; }
+    PC_ON_DEVICE(c);
+    return upload_sets(c, g);
+}
+extern "C" int pc_upload_residues(pc_ctx* c, const pc_packed* g) {
+    if (!c || !g) { pc_set_error("pc_upload_residues: NULL argument"); return PC_ERR_ARG; }
+    if (!c->uploaded) { pc_set_error("pc_upload_residues: pc_upload_sets first"); return PC_ERR_STATE; }
+    PC_ON_DEVICE(c);
+    if (c->residues_ready) return PC_OK;
+    return upload_residues(c, g);
+}
+extern "C" int pc_upload(pc_ctx* c, const pc_packed* g) {
+    if (!c || !g) { pc_set_error("pc_upload: NULL argument"); return PC_ERR_ARG; }
+    PC_ON_DEVICE(c);
+    int rc = upload_sets(c, g);
+    if (rc == PC_OK) rc = upload_residues(c, g);
+    if (rc != PC_OK) c->uploaded = false;
+    return rc;
 }
 
 extern "C" int pc_set_shard(pc_ctx* c, int rank, int world) {
     if (!c || !c->uploaded) { pc_set_error("pc_set_shard: upload first"); return PC_ERR_STATE; }
     if (world < 1 || rank < 0 || rank >= world) { pc_set_error("pc_set_shard: rank %d of %d", rank, world); return PC_ERR_ARG; }
     PC_ON_DEVICE(c);
-    int rc = wait_last_fill(c, nullptr, false); if (rc != PC_OK) return rc;
+    int rc = wait_last_work(c, nullptr, false); if (rc != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(c->stream));
     return apply_shard(c, rank, world);
 }
@@ -495,12 +587,12 @@ extern "C" int pc_set_shard_balanced(pc_ctx* c, int rank, int world) {
     if (!c || !c->uploaded) { pc_set_error("pc_set_shard_balanced: upload first"); return PC_ERR_STATE; }
     if (world < 1 || rank < 0 || rank >= world) { pc_set_error("pc_set_shard_balanced: rank %d of %d", rank, world); return PC_ERR_ARG; }
     PC_ON_DEVICE(c);
-    int rc = wait_last_fill(c, nullptr, false); if (rc != PC_OK) return rc;
+    int rc = wait_last_work(c, nullptr, false); if (rc != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(c->stream));
     const int N = c->dev.N;
     if (c->target_cost.empty()) {
         if ((rc = apply_shard(c, 0, 1))) return rc;                       // walk every pair
-        if ((rc = c->b_cost.ensure((size_t)N * 8)) || (rc = c->b_totals.ensure(64))) return rc;
+        if ((rc = c->b_cost.ensure((size_t)N * 8)) || (rc = c->b_totals.ensure(64))) return abi_rc(rc);
         PC_HIP(hipMemsetAsync(c->b_cost.p, 0, (size_t)N * 8, c->stream));
         PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, c->stream));
         PcWalkArgs a; memset(&a, 0, sizeof(a));
@@ -538,7 +630,9 @@ extern "C" int pc_set_shard_balanced(pc_ctx* c, int rank, int world) {
     if ((rc = upload_vec(c->b_owned, owned)) || (rc = upload_vec(c->b_lbase, lbase)) || (rc = upload_vec(c->b_t_rank, t_rank)) ||
         (rc = upload_vec(c->b_t_lbase, t_lbase))) return rc;
     c->h_t_rank = t_rank; c->h_t_lbase = t_lbase;
+    c->h_owned = owned; c->h_lbase = lbase; c->plan.valid = false;
     c->shard.nown = (int32_t)owned.size();
+    c->shard.ident = world == 1 ? 1 : 0;
     c->shard.owned = c->b_owned.as<int32_t>();
     c->shard.lbase = c->b_lbase.as<int64_t>();
     return PC_OK;
@@ -616,44 +710,124 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
 // ---- the three stages of an aai / peq fill.  pc_fill* run them back to back; the alignment-sliced multi-GPU route
 // (pc_plan_dev, pc_align_slice_dev, pc_reduce_dev) runs them with a collective between the last two.
 
-// PLAN: COUNT, ENUM, sort, distinct alignments, tasks sorted by launch class.  Leaves its results in the context's work
-// buffers and c->plan; three small read-backs.
-static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st) {
+// Memory-bounded batching (the reference never holds more than ~10,000 pairs per CPU in flight, matrix.py:474-493, and so
+// runs any N).  The plan buffers of an aai / peq fill take PC_PLAN_BYTES_PER_ALIGNMENT bytes per alignment; when that
+// exceeds the budget -- or the 2^31-1 alignments a plan can index -- the fill runs plan -> align -> reduce over successive
+// ranges of the shard's target genomes.  Cutting by target keeps every pair's alignments in one chunk.
+#define PC_PLAN_BYTES_PER_ALIGNMENT 56
+#define PC_PLAN_MAX_ALIGNMENTS 0x7ffffffeLL
+
+// Pure host arithmetic, exported for tests: cut [0, n) into consecutive ranges whose sums stay <= max_per_chunk (a single
+// element above it gets a range of its own).  chunk_begin receives the range starts followed by n (at most cap entries are
+// written); returns the number of ranges.
+extern "C" int pc_chunk_plan(const uint64_t* count, int n, uint64_t max_per_chunk, int32_t* chunk_begin, int cap) {
+    if (!count || n < 0 || max_per_chunk == 0) { pc_set_error("pc_chunk_plan: bad argument"); return PC_ERR_ARG; }
+    int nch = 0; uint64_t run = 0;
+    auto put = [&](int v) { if (chunk_begin && nch < cap) chunk_begin[nch] = v; ++nch; };
+    if (n > 0) put(0);
+    for (int k = 0; k < n; ++k) {
+        if (run > 0 && (run + count[k] > max_per_chunk || run + count[k] < run)) { put(k); run = 0; }
+        run += count[k];
+    }
+    if (chunk_begin && nch < cap) chunk_begin[nch] = n;
+    return nch;
+}
+
+extern "C" int pc_set_plan_budget(pc_ctx* c, int64_t bytes) {
+    if (!c || bytes < 0) { pc_set_error("pc_set_plan_budget: bad argument"); return PC_ERR_ARG; }
+    c->plan_budget = bytes;
+    return PC_OK;
+}
+
+// bytes one chunk's plan buffers may take: the caller's figure (pc_set_plan_budget / PC_PLAN_BYTES), else half of what
+// is free now plus what the grow-only plan buffers already hold
+static int64_t plan_budget_bytes(pc_ctx* c) {
+    if (c->plan_budget > 0) return c->plan_budget;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (int64_t)16 << 30; }
+    const size_t held = c->b_key0.cap + c->b_key1.cap + c->b_val0.cap + c->b_val1.cap + c->b_flags.cap + c->b_excl.cap + c->b_alias.cap +
+                        c->b_bucket_row.cap + c->b_res.cap + c->b_sort_tmp.cap;
+    return (int64_t)((free_b + held) / 2);
+}
+static void release_plan_buffers(pc_ctx* c) {
+    DevBuf* bufs[] = {&c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_flags, &c->b_excl, &c->b_alias, &c->b_bucket_row, &c->b_res, &c->b_sort_tmp,
+                      &c->b_tasks, &c->b_tasks_sorted};
+    for (DevBuf* b : bufs) b->release();
+}
+
+// COUNT over the whole shard: alignments per pair (the reference's loop nest, metrics.py:204-224) into b_na, and the
+// totals (alignments, cells, residue bytes); one read-back.
+static int stage_count(pc_ctx* c, int condensed, hipStream_t st, uint64_t tot[3]) {
     int rc = PC_OK;
     const PcDev& d = c->dev;
     const int64_t Lp = c->shard_pairs;
-    pc_ctx::PlanState& P = c->plan;
-    P.valid = false; P.ppos = ppos; P.condensed = condensed; P.A = 0; P.n_distinct = 0; P.ntasks = 0; P.tb.assign(c->ncls_all + 1, 0);
-    memset(&P.st, 0, sizeof(P.st));
-    pc_stats& local = P.st;
-    local.n_pairs = Lp;
     if (d.G > 0 && c->min_gene_len == 0) {
         pc_set_error("fill: an empty translation cannot be aligned (aai/peq); the reference fails on it too"); return PC_ERR_DATA;
     }
-    const int U = d.U;
-    const int ncls = c->ncls_all;
-    const int64_t tmp_fixed = std::max<int64_t>(Lp + 1, U + 1);
-    if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_start_q.ensure((U + 1) * 4)) ||
-        (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) || (rc = c->b_task_off_q.ensure((U + 1) * 4)) ||
-        (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(tmp_fixed) * 4)) || (rc = c->b_totals.ensure(64)) || (rc = c->b_plan.ensure(4096)))
-        return rc;
-    // 1 COUNT: alignments per pair (the reference's loop nest, metrics.py:204-224), totals
+    if ((rc = c->b_na.ensure((Lp + 1) * 4)) || (rc = c->b_off.ensure((Lp + 1) * 4)) || (rc = c->b_totals.ensure(64))) return rc;
     PC_HIP(hipMemsetAsync(c->b_na.p, 0, (Lp + 1) * 4, st));
     PC_HIP(hipMemsetAsync(c->b_totals.p, 0, 64, st));
     PcWalkArgs a; memset(&a, 0, sizeof(a));
     a.na = c->b_na.as<uint32_t>(); a.totals = c->b_totals.as<unsigned long long>();
     a.as_distance = 0; a.condensed = condensed;
     if ((rc = pc_launch_walk(PCW_COUNT, d, c->shard, a, st))) return rc;
-    if ((rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>(), c->b_off.as<uint32_t>(), Lp + 1, c->b_scan_tmp.as<uint32_t>(),
-                                    (int64_t)(c->b_scan_tmp.cap / 4), st))) return rc;
     uint64_t* h_tot = (uint64_t*)(c->h_plan + 1000);
     PC_HIP(hipMemcpyAsync(h_tot, c->b_totals.p, 24, hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));                                     // first read-back: the batch size
-    const uint64_t A = h_tot[0];
-    P.A = (int64_t)A;
-    if (A >= 0x7fffffffULL) { pc_set_error("fill: %llu alignments exceed the 2^31-1 per-call limit; shard the job (pc_set_shard)", (unsigned long long)A); return PC_ERR_LIMIT; }
-    local.n_alignments = (int64_t)A; local.n_cells = (int64_t)h_tot[1]; local.n_residue_bytes = (int64_t)h_tot[2];
+    tot[0] = h_tot[0]; tot[1] = h_tot[1]; tot[2] = h_tot[2];
+    return PC_OK;
+}
+
+// alignments behind each owned target genome (a second COUNT walk, only when a fill has to be cut into chunks)
+static int count_per_target(pc_ctx* c, int condensed, hipStream_t st, std::vector<uint64_t>& per_owned) {
+    int rc = PC_OK;
+    const int N = c->dev.N;
+    if ((rc = c->b_aln_t.ensure((size_t)N * 8))) return rc;
+    PC_HIP(hipMemsetAsync(c->b_aln_t.p, 0, (size_t)N * 8, st));
+    PcWalkArgs a; memset(&a, 0, sizeof(a));
+    a.totals = c->b_totals.as<unsigned long long>() + 5;                  // (slots 5..7: scratch, nobody reads them)
+    a.aln_t = c->b_aln_t.as<unsigned long long>(); a.condensed = condensed;
+    if ((rc = pc_launch_walk(PCW_COUNT, c->dev, c->shard, a, st))) return rc;
+    std::vector<uint64_t> all(N);
+    PC_HIP(hipMemcpyAsync(all.data(), c->b_aln_t.p, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    per_owned.resize(c->h_owned.size());
+    for (size_t k = 0; k < c->h_owned.size(); ++k) per_owned[k] = all[c->h_owned[k]];
+    return PC_OK;
+}
+
+// PLAN of the owned targets [k0, k1) holding A alignments (b_na is filled): scan, ENUM, sort, distinct alignments, tasks
+// sorted by launch class.  Leaves its results in the context's work buffers and c->plan; two small read-backs.
+static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st, int k0, int k1, uint64_t A) {
+    int rc = PC_OK;
+    PlanningScope planning;
+    const PcDev& d = c->dev;
+    pc_ctx::PlanState& P = c->plan;
+    P.valid = false; P.ppos = ppos; P.condensed = condensed; P.A = (int64_t)A; P.n_distinct = 0; P.ntasks = 0; P.tb.assign(c->ncls_all + 1, 0);
+    P.k0 = k0; P.k1 = k1; P.whole = c->world == 1 && condensed == 1 && k0 == 0 && k1 == c->shard.nown;
+    memset(&P.st, 0, sizeof(P.st));
+    pc_stats& local = P.st;
+    const int64_t base = c->h_lbase[k0], Lc = c->h_lbase[k1] - base;
+    local.n_pairs = Lc;
+    local.n_alignments = (int64_t)A;
+    if (A > (uint64_t)PC_PLAN_MAX_ALIGNMENTS) {
+        pc_set_error("plan: %llu alignments behind ONE target genome exceed the 2^31-2 a plan can index", (unsigned long long)A); return PC_ERR_LIMIT;
+    }
+    const int U = d.U;
+    const int ncls = c->ncls_all;
+    const int64_t tmp_fixed = std::max<int64_t>(Lc + 1, U + 1);
+    if ((rc = c->b_start_q.ensure((U + 1) * 4)) || (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) ||
+        (rc = c->b_task_off_q.ensure((U + 1) * 4)) || (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(tmp_fixed) * 4)) || (rc = c->b_plan.ensure(4096)))
+        return rc;
+    // alignment slot of a pair = exclusive scan of the chunk's counts (slots start at 0 in every chunk)
+    if (Lc > 0 && (rc = pc_scan_exclusive_u32(c->b_na.as<uint32_t>() + base, c->b_off.as<uint32_t>() + base, Lc, c->b_scan_tmp.as<uint32_t>(),
+                                              (int64_t)(c->b_scan_tmp.cap / 4), st))) return rc;
+    PcShard sub = c->shard;
+    sub.nown = k1 - k0; sub.owned = c->shard.owned + k0; sub.lbase = c->shard.lbase + k0; sub.ident = c->shard.ident && k0 == 0;
+    PcWalkArgs a; memset(&a, 0, sizeof(a));
+    a.as_distance = 0; a.condensed = condensed;
     a.off = c->b_off.as<uint32_t>();
+    uint64_t* h_tot = (uint64_t*)(c->h_plan + 1000);
     if (A > 0) {
         const int64_t An = (int64_t)A;
         const int key_bits = 2 * d.ubits;
@@ -666,13 +840,14 @@ static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st) {
         const int64_t tmp_elems = (int64_t)(c->b_scan_tmp.cap / 4);
         // 2 ENUM: one sort key per alignment slot; 3 sort; 4 distinct alignments, aliases, buckets (pc_plan.hip)
         a.key = c->b_key0.as<unsigned long long>(); a.val = c->b_val0.as<uint32_t>();
-        if ((rc = pc_launch_walk(PCW_ENUM, d, c->shard, a, st))) return rc;
+        if ((rc = pc_launch_walk(PCW_ENUM, d, sub, a, st))) return rc;
         if ((rc = pc_sort_pairs(c->b_sort_tmp.p, c->b_sort_tmp.cap, c->b_key0.as<unsigned long long>(), c->b_key1.as<unsigned long long>(),
                                 c->b_val0.as<uint32_t>(), c->b_val1.as<uint32_t>(), An, key_bits, st))) return rc;
         if ((rc = pc_launch_mark_heads(c->b_key1.as<unsigned long long>(), c->b_flags.as<uint32_t>(), An, st))) return rc;
         if ((rc = pc_scan_exclusive_u32(c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(), An + 1, c->b_scan_tmp.as<uint32_t>(), tmp_elems, st))) return rc;
         PC_HIP(hipMemsetAsync(c->b_start_q.p, 0, (U + 1) * 4, st));
         PC_HIP(hipMemsetAsync(c->b_end_q.p, 0, (U + 1) * 4, st));
+        PC_HIP(hipMemsetAsync(c->b_totals.as<unsigned long long>() + 3, 0, 16, st));        // distinct alignments / cells of THIS chunk
         if ((rc = pc_launch_unique(d, c->b_key1.as<unsigned long long>(), c->b_val1.as<uint32_t>(), c->b_flags.as<uint32_t>(), c->b_excl.as<uint32_t>(),
                                    c->b_alias.as<uint32_t>(), c->b_bucket_row.as<int32_t>(), c->b_start_q.as<uint32_t>(), c->b_end_q.as<uint32_t>(),
                                    c->b_totals.as<unsigned long long>(), An, st))) return rc;
@@ -736,14 +911,93 @@ static int stage_align(pc_ctx* c, int slice_rank, int slice_world, uint2* res, h
     return run_align_classes(c, task_list, tb.data(), c->cls_max_lb.data(), res, st, stats, P.ppos);
 }
 
-// REDUCE: best match per anchor gene through the aliases, fp64 epilogue (metrics.py:204-232, 247-253)
+// REDUCE: best match per anchor gene through the aliases, fp64 epilogue (metrics.py:204-232, 247-253), over the plan's targets
 static int stage_reduce(pc_ctx* c, int metric, int as_distance, const uint2* res, double* out, hipStream_t st) {
     pc_ctx::PlanState& P = c->plan;
     if (!P.valid) { pc_set_error("reduce: no plan (pc_plan_dev first)"); return PC_ERR_STATE; }
+    PcShard sub = c->shard;
+    sub.nown = P.k1 - P.k0; sub.owned = c->shard.owned + P.k0; sub.lbase = c->shard.lbase + P.k0; sub.ident = c->shard.ident && P.k0 == 0;
     PcWalkArgs a; memset(&a, 0, sizeof(a));
     a.off = c->b_off.as<uint32_t>(); a.alias = c->b_alias.as<uint32_t>(); a.res = res; a.out = out;
     a.as_distance = as_distance ? 1 : 0; a.condensed = P.condensed;
-    return pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, c->dev, c->shard, a, st);
+    return pc_launch_walk(metric == PC_AAI ? PCW_AAI : PCW_PEQ, c->dev, sub, a, st);
+}
+
+static void add_plan_stats(pc_stats& acc, const pc_stats& ps) {
+    acc.n_tasks += ps.n_tasks; acc.n_distinct_alignments += ps.n_distinct_alignments; acc.n_distinct_cells += ps.n_distinct_cells;
+}
+
+// aai / peq: COUNT once, then plan -> align -> reduce -- in one piece when the plan fits the budget, else chunk by chunk
+static int fill_aligned(pc_ctx* c, int metric, int ppos, int as_distance, double* out, int condensed, hipStream_t st, pc_stats& local, bool timed) {
+    int rc = PC_OK;
+    if (!c->residues_ready) { pc_set_error("fill: aai / peq need the residues on the device (pc_upload, or pc_upload_residues after pc_upload_sets)"); return PC_ERR_STATE; }
+    uint64_t tot[3] = {0, 0, 0};
+    if ((rc = stage_count(c, condensed, st, tot))) return rc;
+    local.n_alignments = (int64_t)tot[0]; local.n_cells = (int64_t)tot[1]; local.n_residue_bytes = (int64_t)tot[2];
+    const int nown = c->shard.nown;
+    const uint64_t A = tot[0];
+    // does the whole plan fit?  (hipMemGetInfo only when the question is open: plans under 1 GiB always do)
+    uint64_t max_aln = (uint64_t)PC_PLAN_MAX_ALIGNMENTS;
+    if (c->plan_budget > 0 || A * PC_PLAN_BYTES_PER_ALIGNMENT > ((uint64_t)1 << 30))
+        max_aln = std::min<uint64_t>(max_aln, (uint64_t)std::max<int64_t>(plan_budget_bytes(c) / PC_PLAN_BYTES_PER_ALIGNMENT, 1));
+    local.n_chunks = 0;
+    if (A <= max_aln) {
+        rc = stage_plan(c, ppos, condensed, st, 0, nown, A);
+        if (rc == PC_OK) {
+            PC_HIP(hipEventRecord(c->ev[1], st));
+            rc = stage_align(c, 0, 1, c->b_res.as<uint2>(), st, &local);
+        }
+        if (rc == PC_OK) {
+            PC_HIP(hipEventRecord(c->ev[2], st));
+            rc = stage_reduce(c, metric, as_distance, c->b_res.as<uint2>(), out, st);
+        }
+        if (rc == PC_OK) {
+            add_plan_stats(local, c->plan.st);
+            local.n_chunks = 1;
+            PC_HIP(hipEventRecord(c->ev[3], st));
+            return PC_OK;
+        }
+        if (rc != PC_ERR_NOMEM_INTERNAL) return rc;
+        PC_HIP(hipStreamSynchronize(st));                                 // out of HBM: free the plan, go on in chunks of half the size
+        release_plan_buffers(c);
+        max_aln = std::max<uint64_t>(A / 2, 1);
+        local.n_tasks = 0; local.n_distinct_alignments = local.n_distinct_cells = 0; local.n_align_launches = 0;
+    }
+    // ---- chunked: successive ranges of the owned targets, each planned, aligned and reduced before the next
+    std::vector<uint64_t> per_owned;
+    if ((rc = count_per_target(c, condensed, st, per_owned))) return rc;
+    float ms_plan = 0.f, ms_align = 0.f, ms_reduce = 0.f;
+    int k = 0, nchunks = 0;
+    while (k < nown) {
+        // the next chunk: as many targets from k on as stay within max_aln (pc_chunk_plan's rule)
+        uint64_t run = per_owned[k]; int k1 = k + 1;
+        while (k1 < nown && run + per_owned[k1] <= max_aln) { run += per_owned[k1]; ++k1; }
+        if (timed) PC_HIP(hipEventRecord(c->ev[4], st));
+        rc = stage_plan(c, ppos, condensed, st, k, k1, run);
+        if (rc == PC_OK) { if (timed) PC_HIP(hipEventRecord(c->ev[1], st)); rc = stage_align(c, 0, 1, c->b_res.as<uint2>(), st, &local); }
+        if (rc == PC_OK) { if (timed) PC_HIP(hipEventRecord(c->ev[2], st)); rc = stage_reduce(c, metric, as_distance, c->b_res.as<uint2>(), out, st); }
+        if (rc == PC_ERR_NOMEM_INTERNAL && max_aln > 1 && k1 - k > 1) {                 // a retry with a smaller chunk, not an error
+            PC_HIP(hipStreamSynchronize(st));
+            release_plan_buffers(c);
+            max_aln = std::max<uint64_t>(std::min(max_aln, run) / 2, 1);
+            continue;
+        }
+        if (rc != PC_OK) return rc;
+        PC_HIP(hipEventRecord(c->ev[3], st));
+        add_plan_stats(local, c->plan.st);
+        if (timed) {
+            float x = 0.f;
+            PC_HIP(hipEventSynchronize(c->ev[3]));
+            PC_HIP(hipEventElapsedTime(&x, c->ev[4], c->ev[1])); ms_plan += x;
+            PC_HIP(hipEventElapsedTime(&x, c->ev[1], c->ev[2])); ms_align += x;
+            PC_HIP(hipEventElapsedTime(&x, c->ev[2], c->ev[3])); ms_reduce += x;
+        }
+        ++nchunks; k = k1;
+    }
+    c->plan.valid = false;                                                // the last chunk's plan is not "the plan of the fill"
+    local.n_chunks = nchunks;
+    local.ms_plan = ms_plan; local.ms_align = ms_align; local.ms_reduce = ms_reduce;
+    return PC_OK;
 }
 
 static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
@@ -756,7 +1010,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     int rc = PC_OK;
     // st == NULL is HIP's legacy default stream, used as such: a caller whose producers / consumers run on it (PyTorch's
     // default stream has handle 0) is ordered with these launches; the library's own streams are non-blocking
-    if ((rc = wait_last_fill(c, st, true))) return rc;
+    if ((rc = wait_last_work(c, st, true))) return rc;
     const PcDev& d = c->dev;
     const int64_t Lp = c->shard_pairs;
     pc_stats local; memset(&local, 0, sizeof(local));
@@ -765,41 +1019,43 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     PC_HIP(hipEventRecord(c->ev[0], st));
 
     if (metric == PC_GCS || metric == PC_JC) {
-        // epilogue table over (shared, nph_s + nph_t): at most (max_nph+1) x (2 max_nph+1) doubles; skipped when huge
+        // epilogue table over (shared, nph_s + nph_t): at most (max_nph+1) x (2 max_nph+1) doubles; skipped when huge.
+        // It depends on (metric, as_distance, max_nph) only, so it is rebuilt only when one of them changes.
         const int sh_dim = c->max_nph + 1, tot_dim = 2 * c->max_nph + 1;
-        double* lut = nullptr;
+        double* lut = nullptr; bool build_lut = false;
         if ((int64_t)sh_dim * tot_dim <= (4 << 20)) {
-            if ((rc = c->b_lut.ensure((size_t)sh_dim * tot_dim * 8))) return rc;
+            if ((rc = c->b_lut.ensure((size_t)sh_dim * tot_dim * 8))) return rc == PC_ERR_NOMEM_INTERNAL ? PC_ERR_HIP : rc;
             lut = c->b_lut.as<double>();
+            const int64_t key = ((int64_t)metric << 40) | ((int64_t)as_distance << 32) | (int64_t)c->max_nph;
+            build_lut = key != c->lut_key || lut != c->lut_ptr;
+            c->lut_key = key; c->lut_ptr = lut;
         }
-        rc = pc_launch_set_popc(d, c->shard, metric, as_distance, out, condensed, lut, sh_dim, tot_dim, st);
+        rc = pc_launch_set_popc(d, c->shard, metric, as_distance, out, condensed, lut, build_lut, sh_dim, tot_dim, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
+        local.n_chunks = 1;
     } else if (metric == PC_POCP || metric == PC_AF) {
         PcWalkArgs a; memset(&a, 0, sizeof(a));
         a.out = out; a.as_distance = as_distance; a.condensed = condensed;
         rc = pc_launch_walk(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, a, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
+        local.n_chunks = 1;
     } else {
-        if ((rc = stage_plan(c, ppos, condensed, st))) return rc;
-        PC_HIP(hipEventRecord(c->ev[1], st));
-        if ((rc = stage_align(c, 0, 1, c->b_res.as<uint2>(), st, &local))) return rc;
-        PC_HIP(hipEventRecord(c->ev[2], st));
-        if ((rc = stage_reduce(c, metric, as_distance, c->b_res.as<uint2>(), out, st))) return rc;
-        { const pc_stats& ps = c->plan.st; local.n_alignments = ps.n_alignments; local.n_cells = ps.n_cells; local.n_residue_bytes = ps.n_residue_bytes;
-          local.n_tasks = ps.n_tasks; local.n_distinct_alignments = ps.n_distinct_alignments; local.n_distinct_cells = ps.n_distinct_cells; }
-        PC_HIP(hipEventRecord(c->ev[3], st));
+        rc = fill_aligned(c, metric, ppos, as_distance, out, condensed, st, local, stats != nullptr);
+        if (rc != PC_OK) { (void)mark_work(c, st); return rc == PC_ERR_NOMEM_INTERNAL ? PC_ERR_HIP : rc; }
     }
-    c->busy = true; c->last_stream = st;
+    if ((rc = mark_work(c, st))) return rc;
     if (stats) {
         PC_HIP(hipEventSynchronize(c->ev[3]));
         c->busy = false;
         PC_HIP(hipEventElapsedTime(&local.ms_total, c->ev[0], c->ev[3]));
         if (metric >= PC_AAI) {
-            PC_HIP(hipEventElapsedTime(&local.ms_plan, c->ev[0], c->ev[1]));
-            PC_HIP(hipEventElapsedTime(&local.ms_align, c->ev[1], c->ev[2]));
-            PC_HIP(hipEventElapsedTime(&local.ms_reduce, c->ev[2], c->ev[3]));
+            if (local.n_chunks == 1) {
+                PC_HIP(hipEventElapsedTime(&local.ms_plan, c->ev[0], c->ev[1]));
+                PC_HIP(hipEventElapsedTime(&local.ms_align, c->ev[1], c->ev[2]));
+                PC_HIP(hipEventElapsedTime(&local.ms_reduce, c->ev[2], c->ev[3]));
+            }
         } else {
             local.ms_reduce = local.ms_total;
         }
@@ -816,16 +1072,29 @@ extern "C" int pc_plan_dev(pc_ctx* c, int metric, void* stream, pc_stats* stats)
     if (!c || !c->uploaded) { pc_set_error("pc_plan_dev: upload first"); return PC_ERR_STATE; }
     if (metric != PC_AAI && metric != PC_PEQ && metric != PC_AAI_PPOS) { pc_set_error("pc_plan_dev: metric %d has no alignment plan", metric); return PC_ERR_ARG; }
     if (c->world != 1) { pc_set_error("pc_plan_dev: context is sharded (%d/%d); the alignment-sliced route plans the whole matrix", c->rank, c->world); return PC_ERR_STATE; }
+    if (!c->residues_ready) { pc_set_error("pc_plan_dev: the residues are not on the device (pc_upload_residues)"); return PC_ERR_STATE; }
     PC_ON_DEVICE(c);
     hipStream_t st = (hipStream_t)stream;
-    int rc = wait_last_fill(c, st, true); if (rc != PC_OK) return rc;
+    int rc = wait_last_work(c, st, true); if (rc != PC_OK) return rc;
     PC_HIP(hipEventRecord(c->ev[0], st));
-    if ((rc = stage_plan(c, metric == PC_AAI_PPOS, 1, st))) return rc;
+    uint64_t tot[3] = {0, 0, 0};
+    if ((rc = stage_count(c, 1, st, tot))) return abi_rc(rc);
+    if (tot[0] > (uint64_t)PC_PLAN_MAX_ALIGNMENTS) {
+        pc_set_error("pc_plan_dev: %llu alignments exceed the 2^31-2 one plan can index; the alignment-sliced route keeps the whole plan resident "
+                     "-- use the pair-sharded route (pc_fill_shard_dev), which fills in chunks", (unsigned long long)tot[0]);
+        return PC_ERR_LIMIT;
+    }
+    rc = stage_plan(c, metric == PC_AAI_PPOS, 1, st, 0, c->shard.nown, tot[0]);
+    (void)mark_work(c, st);
+    if (rc != PC_OK) return abi_rc(rc);
+    c->plan.st.n_cells = (int64_t)tot[1]; c->plan.st.n_residue_bytes = (int64_t)tot[2];
     PC_HIP(hipEventRecord(c->ev[1], st));
-    c->busy = true; c->last_stream = st;
+    if ((rc = mark_work(c, st))) return rc;
     if (stats) {
         PC_HIP(hipEventSynchronize(c->ev[1]));
+        c->busy = false;
         *stats = c->plan.st;
+        stats->n_chunks = 1;
         PC_HIP(hipEventElapsedTime(&stats->ms_plan, c->ev[0], c->ev[1]));
         stats->ms_total = stats->ms_plan;
     }
@@ -834,19 +1103,26 @@ extern "C" int pc_plan_dev(pc_ctx* c, int metric, void* stream, pc_stats* stats)
 
 extern "C" int pc_align_slice_dev(pc_ctx* c, int slice_rank, int slice_world, void* res_dev, void* stream, pc_stats* stats) {
     if (!c || !c->uploaded || !c->plan.valid) { pc_set_error("pc_align_slice_dev: pc_plan_dev first"); return PC_ERR_STATE; }
+    if (!c->plan.whole) { pc_set_error("pc_align_slice_dev: the plan in the context is not a whole-matrix plan of an unsharded context (pc_plan_dev)"); return PC_ERR_STATE; }
     if (slice_world < 1 || slice_rank < 0 || slice_rank >= slice_world) { pc_set_error("pc_align_slice_dev: slice %d of %d", slice_rank, slice_world); return PC_ERR_ARG; }
     if (!res_dev && c->plan.n_distinct > 0) { pc_set_error("pc_align_slice_dev: res_dev is NULL"); return PC_ERR_ARG; }
     PC_ON_DEVICE(c);
     hipStream_t st = (hipStream_t)stream;
+    // a slice still running on ANOTHER stream reads the task tables this call rewrites
+    int rc = wait_last_work(c, st, true); if (rc != PC_OK) return rc;
     pc_stats local = c->plan.st;
     PC_HIP(hipEventRecord(c->ev[1], st));
-    int rc = stage_align(c, slice_rank, slice_world, (uint2*)res_dev, st, &local); if (rc != PC_OK) return rc;
+    rc = stage_align(c, slice_rank, slice_world, (uint2*)res_dev, st, &local);
     PC_HIP(hipEventRecord(c->ev[2], st));
-    c->busy = true; c->last_stream = st;
+    int rc2 = mark_work(c, st);
+    if (rc != PC_OK) return abi_rc(rc);
+    if (rc2 != PC_OK) return rc2;
     if (stats) {
         PC_HIP(hipEventSynchronize(c->ev[2]));
+        c->busy = false;
         PC_HIP(hipEventElapsedTime(&local.ms_align, c->ev[1], c->ev[2]));
         local.ms_total = local.ms_align;
+        local.n_chunks = 1;
         *stats = local;
     }
     return PC_OK;
@@ -854,15 +1130,16 @@ extern "C" int pc_align_slice_dev(pc_ctx* c, int slice_rank, int slice_world, vo
 
 extern "C" int pc_reduce_dev(pc_ctx* c, int metric, int as_distance, const void* res_dev, void* out_condensed_dev, void* stream) {
     if (!c || !c->uploaded || !c->plan.valid) { pc_set_error("pc_reduce_dev: pc_plan_dev first"); return PC_ERR_STATE; }
+    if (!c->plan.whole) { pc_set_error("pc_reduce_dev: the plan in the context is not a whole-matrix plan of an unsharded context (pc_plan_dev)"); return PC_ERR_STATE; }
     if (metric == PC_AAI_PPOS) metric = PC_AAI;
     if (metric != PC_AAI && metric != PC_PEQ) { pc_set_error("pc_reduce_dev: metric %d", metric); return PC_ERR_ARG; }
     if (!out_condensed_dev || (!res_dev && c->plan.n_distinct > 0)) { pc_set_error("pc_reduce_dev: NULL argument"); return PC_ERR_ARG; }
     PC_ON_DEVICE(c);
     hipStream_t st = (hipStream_t)stream;
-    int rc = stage_reduce(c, metric, as_distance, (const uint2*)res_dev, (double*)out_condensed_dev, st); if (rc != PC_OK) return rc;
-    PC_HIP(hipEventRecord(c->ev[3], st));
-    c->busy = true; c->last_stream = st;
-    return PC_OK;
+    int rc = wait_last_work(c, st, true); if (rc != PC_OK) return rc;
+    rc = stage_reduce(c, metric, as_distance, (const uint2*)res_dev, (double*)out_condensed_dev, st);
+    int rc2 = mark_work(c, st);
+    return rc != PC_OK ? abi_rc(rc) : rc2;
 }
 
 extern "C" int pc_fill_dev(pc_ctx* c, int metric, int as_distance, void* out_dev, void* stream, pc_stats* stats) {
@@ -876,7 +1153,7 @@ extern "C" int pc_fill(pc_ctx* c, int metric, int as_distance, double* out_conde
     PC_ON_DEVICE(c);
     int rc = PC_OK;
     const int64_t np = (int64_t)c->dev.N * (c->dev.N - 1) / 2;
-    if ((rc = c->b_out.ensure(std::max<int64_t>(np, 1) * 8))) return rc;
+    if ((rc = c->b_out.ensure(std::max<int64_t>(np, 1) * 8))) return abi_rc(rc);
     if ((rc = pc_fill_dev(c, metric, as_distance, c->b_out.p, c->stream, stats))) return rc;
     if (np) PC_HIP(hipMemcpyAsync(out_condensed, c->b_out.p, np * 8, hipMemcpyDeviceToHost, c->stream));
     PC_HIP(hipStreamSynchronize(c->stream));
@@ -895,7 +1172,7 @@ extern "C" int pc_fill_borrow(pc_ctx* c, int metric, int as_distance, const doub
     int rc = PC_OK;
     const int64_t np = (int64_t)c->dev.N * (c->dev.N - 1) / 2;
     const size_t bytes = (size_t)std::max<int64_t>(np, 1) * 8;
-    if ((rc = c->b_out.ensure(bytes))) return rc;
+    if ((rc = c->b_out.ensure(bytes))) return abi_rc(rc);
     if (bytes > c->h_out_cap) {
         if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; }
         const size_t want = bytes + bytes / 8;
@@ -937,8 +1214,10 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
     if (n < 0 || (n > 0 && (!a_gene || !b_gene || !n_ident || !n_diag))) { pc_set_error("pc_align_pairs: NULL argument"); return PC_ERR_ARG; }
     if (n == 0) return PC_OK;
     if (n >= 0x7fffffffLL) { pc_set_error("pc_align_pairs: too many pairs"); return PC_ERR_LIMIT; }
+    if (!c->residues_ready) { pc_set_error("pc_align_pairs: the residues are not on the device (pc_upload_residues)"); return PC_ERR_STATE; }
     PC_ON_DEVICE(c);
-    int rc = wait_last_fill(c, nullptr, false); if (rc != PC_OK) return rc;
+    int rc = wait_last_work(c, nullptr, false); if (rc != PC_OK) return rc;
+    c->plan.valid = false;                             // this call reuses the plan's task, bucket and result buffers
     const int G = c->dev.G;
     const int nvar = pc_nw_num_variants();
     int forced = -2;                                   // -2: automatic
@@ -999,7 +1278,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
     hipStream_t st = c->stream;
     auto cleanup = [&]() { d_sums.release(); d_ident.release(); d_diag.release(); };
     if ((rc = upload_vec(c->b_bucket_row, rows)) || (rc = upload_vec(c->b_bucket_dest, dest)) || (rc = upload_vec(c->b_tasks, tasks)) ||
-        (rc = c->b_res.ensure(n * 8)) || (rc = upload_vec(d_sums, sums)) || (rc = d_ident.ensure(n * 4)) || (rc = d_diag.ensure(n * 4))) { cleanup(); return rc; }
+        (rc = c->b_res.ensure(n * 8)) || (rc = upload_vec(d_sums, sums)) || (rc = d_ident.ensure(n * 4)) || (rc = d_diag.ensure(n * 4))) { cleanup(); return abi_rc(rc); }
     (void)hipEventRecord(c->ev[1], st);
     for (int cl = 0; cl < ncls_all; ++cl) {
         const int nt = (int)(cls_task_begin[cl + 1] - cls_task_begin[cl]);
@@ -1008,7 +1287,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         const int v = pc_class_variant(cl);
         if (v < 0) {
             sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[cl]);
-            if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return rc; }
+            if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return abi_rc(rc); }
             scratch = c->b_scratch.p;
         }
         rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[cl], nt, c->b_bucket_row.as<int32_t>(),
@@ -1028,6 +1307,11 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
     return rc;
 }
 
+extern "C" int pc_variant_width(int lb) {
+    const int v = pc_nw_choose_variant(lb);
+    return v < 0 ? 0 : pc_nw_variant_w(v);
+}
+
 extern "C" float pc_last_align_ms(const pc_ctx* c) { return c ? c->last_align_ms : -1.f; }
 
 extern "C" int pc_set_tie_rule(pc_ctx* c, int rule) {
@@ -1045,7 +1329,7 @@ extern "C" int pc_round6_probe(pc_ctx* c, const double* in, double* out, int64_t
     PC_ON_DEVICE(c);
     int rc = PC_OK;
     DevBuf a, b;
-    if ((rc = a.ensure(n * 8)) || (rc = b.ensure(n * 8))) { a.release(); b.release(); return rc; }
+    if ((rc = a.ensure(n * 8)) || (rc = b.ensure(n * 8))) { a.release(); b.release(); return abi_rc(rc); }
     hipError_t e = hipMemcpyAsync(a.p, in, n * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) { rc = pc_launch_round6_probe(a.as<double>(), b.as<double>(), n, c->stream); }
     if (e == hipSuccess && rc == PC_OK) e = hipMemcpyAsync(out, b.p, n * 8, hipMemcpyDeviceToHost, c->stream);

@@ -37,6 +37,7 @@ struct PcDev {
 // Static shard: the target genomes this rank owns, ascending.
 struct PcShard {
     int32_t nown;
+    int32_t ident;                    // 1: owned[k] == k for every k (an unsharded context): kernels skip the table read
     const int32_t* owned;             // [nown] target genome t
     const int64_t* lbase;             // [nown+1] shard-local index of pair (0, owned[k]); pair (s,t) -> lbase[k] + s
 };
@@ -60,6 +61,7 @@ struct PcWalkArgs {
     uint32_t* na;                     // [Lp] alignments per pair
     unsigned long long* totals;       // [0] alignments [1] cells [2] residue bytes (as the reference would run them)
     unsigned long long* cost_t;       // [N] or NULL: DP cells per target genome (input of the cost-balanced deal)
+    unsigned long long* aln_t;        // [N] or NULL: alignments per target genome (where a fill that exceeds its memory budget is cut)
     // ENUM: alignment slot k of a pair = off[pair] + its position in the reference's loop order
     const uint32_t* off;              // [Lp] exclusive scan of na
     unsigned long long* key;          // [A] (column sequence rank << ubits) | row sequence rank
@@ -84,7 +86,7 @@ void pc_set_error(const char* fmt, ...);
 
 // launchers (defined next to their kernels)
 int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed,
-                       double* lut, int sh_dim, int tot_dim, hipStream_t st);
+                       double* lut, bool build_lut, int sh_dim, int tot_dim, hipStream_t st);
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);

@@ -130,7 +130,6 @@ __device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh,
 // looked up in a table built once per fill by k_set_lut (exactly the same fp64 code path:
 // division, 1 - x, round(., 6)); without a table (huge genomes) it is computed in place.
 // ---------------------------------------------------------------------------------
-#define PT 64          // popcount tile edge
 #define PWCH 32        // bitmap words staged per chunk
 
 template <int METRIC>
@@ -153,16 +152,20 @@ __global__ void k_set_lut(double* __restrict__ lut, int sh_dim, int tot_dim, int
     lut[i] = possible ? pc_set_value<METRIC>(shared, tot, as_distance) : 0.0;
 }
 
+// target genome of shard slot k (an unsharded context owns every genome in order: no table read on the critical path)
+__device__ __forceinline__ int pc_owned(const PcShard& sh, int k) { return sh.ident ? k : sh.owned[k]; }
+
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
                                                    const double* __restrict__ lut, int sh_dim) {
+    constexpr int PT = 64;
     __shared__ uint64_t rs[PT][PWCH + 1];
     __shared__ uint64_t rt[PT][PWCH + 1];
     int tile_x, tile_y;
     if (!pc_tile_of_block((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT, tile_x, tile_y)) return;
     const int s0 = tile_x * PT, k0 = tile_y * PT;
     const int klast = min(k0 + PT, sh.nown) - 1;
-    if (s0 >= sh.owned[klast]) return;                       // tile entirely on/below the diagonal
+    if (s0 >= pc_owned(sh, klast)) return;                   // tile entirely on/below the diagonal
     // 256 threads = 16 (fx) x 16 (fy), a 4x4 register tile of pairs each: per bitmap word a thread reads 4 + 4 row words
     // from LDS for 16 AND+popcount pairs (0.5 LDS reads per pair-word: the loop is VALU-bound -- v_and at 2 clocks and
     // v_bcnt at 4 per wave64, profiles/valu_issue_rate.json -- not LDS-bound).  fx runs along the output's contiguous
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
     for (int p = 0; p < 8; ++p) {
         const int s = s0 + r0 + 8 * p, k = k0 + r0 + 8 * p;
         ps[p] = s < d.N ? d.bitmap + (int64_t)s * d.Wstride : nullptr;
-        pt[p] = k < sh.nown ? d.bitmap + (int64_t)sh.owned[k] * d.Wstride : nullptr;
+        pt[p] = k < sh.nown ? d.bitmap + (int64_t)pc_owned(sh, k) * d.Wstride : nullptr;
     }
     uint64_t vs[8], vt[8];
     auto fetch = [&](int w0) {
@@ -203,7 +206,6 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
         for (int p = 0; p < 8; ++p) { rs[r0 + 8 * p][wl] = vs[p]; rt[r0 + 8 * p][wl] = vt[p]; }
         __syncthreads();
         if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
-#pragma unroll 2
         for (int w = 0; w < wn; ++w) {
             uint64_t a[4], b[4];
 #pragma unroll
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
             const int lt = condensed ? fx + 16 * j : fy + 16 * i;
             const int s = s0 + ls, k = k0 + lt;
             if (s >= d.N || k >= sh.nown) continue;
-            const int t = sh.owned[k];
+            const int t = pc_owned(sh, k);
             if (s >= t) continue;
             const int shared = acc[i][j], tot = d.nph[s] + d.nph[t];
             const double v = lut ? lut[tot * sh_dim + shared] : pc_set_value<METRIC>(shared, tot, as_distance);
@@ -238,17 +240,130 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
     }
 }
 
+// The same for SMALL matrices: 32x32-pair tiles, and the four waves of a workgroup split the bitmap WORDS of the tile
+// between them (wave v counts words v, v+4, ... of every chunk for all 32x32 pairs, 4x4 per lane), then add their partial
+// counts through LDS and each finishes a quarter of the pairs.  At N = 2,000 (BASELINE configs[1]) the 64x64 kernel is 528
+// live workgroups of ~11 us per wave on 256 CUs: two waves on most SIMDs, three on some, and the kernel lasts as long as
+// the three (51 us against a 16 us popcount floor; counting alone 32 us, `tools/popc_experiment.sh`).  Here a wave carries
+// a quarter of that, so 8,064 of them deal out evenly, and the ~8 waves per SIMD hide each other's LDS and staging waits.
+// The staging buffers double as the partial-sum array once the last chunk has been counted.
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
+                                                          const double* __restrict__ lut, int sh_dim) {
+    constexpr int PT = 32;
+    __shared__ uint64_t lds[2 * PT * (PWCH + 1)];                   // rs, rt; later int part[4][16][64] (16,384 of its 16,896 bytes)
+    uint64_t (*rs)[PWCH + 1] = (uint64_t (*)[PWCH + 1])lds;
+    uint64_t (*rt)[PWCH + 1] = (uint64_t (*)[PWCH + 1])(lds + PT * (PWCH + 1));
+    int tile_x, tile_y;
+    if (!pc_tile_of_block((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT, tile_x, tile_y)) return;
+    const int s0 = tile_x * PT, k0 = tile_y * PT;
+    const int klast = min(k0 + PT, sh.nown) - 1;
+    if (s0 >= pc_owned(sh, klast)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int fx = lane & 7, fy = lane >> 3;
+    // the pairs this lane FINISHES: register-tile row `wave`, columns 0..3; their nph are fetched now, off the critical path
+    int fin_s[4], fin_k[4], fin_t[4], fin_tot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ls = condensed ? fy + 8 * wave : fx + 8 * j, lt = condensed ? fx + 8 * j : fy + 8 * wave;
+        fin_s[j] = s0 + ls; fin_k[j] = k0 + lt;
+        const bool ok = fin_s[j] < d.N && fin_k[j] < sh.nown;
+        fin_t[j] = ok ? pc_owned(sh, fin_k[j]) : 0;
+        fin_tot[j] = ok && fin_s[j] < fin_t[j] ? d.nph[fin_s[j]] + d.nph[fin_t[j]] : -1;     // -1: no such pair
+    }
+    int acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    // staging: thread (r0 = tid>>5, w = tid&31) moves word w of rows r0 + 8p (p < 4) of both tiles
+    const int r0 = threadIdx.x >> 5, wl = threadIdx.x & 31;
+    const uint64_t* ps[4]; const uint64_t* pt[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = s0 + r0 + 8 * p, k = k0 + r0 + 8 * p;
+        ps[p] = s < d.N ? d.bitmap + (int64_t)s * d.Wstride : nullptr;
+        pt[p] = k < sh.nown ? d.bitmap + (int64_t)pc_owned(sh, k) * d.Wstride : nullptr;
+    }
+    uint64_t vs[4], vt[4];
+    auto fetch = [&](int w0) {
+        const int w = w0 + wl;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            vs[p] = (ps[p] && w < d.Wb) ? ps[p][w] : 0ULL;
+            vt[p] = (pt[p] && w < d.Wb) ? pt[p][w] : 0ULL;
+        }
+    };
+    uint64_t (*ra)[PWCH + 1] = condensed ? rs : rt;
+    uint64_t (*rb)[PWCH + 1] = condensed ? rt : rs;
+    fetch(0);
+    for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
+        const int wn = min(PWCH, d.Wb - w0);
+        if (w0) __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { rs[r0 + 8 * p][wl] = vs[p]; rt[r0 + 8 * p][wl] = vt[p]; }
+        __syncthreads();
+        if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
+#pragma unroll
+        for (int q = 0; q < PWCH / 4; ++q) {
+            const int w = wave + 4 * q;                              // wave-uniform
+            if (w >= wn) break;
+            uint64_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ra[fy + 8 * i][w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = rb[fx + 8 * j][w];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t x = a[i] & b[j];
+                    asm("v_bcnt_u32_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %2, %0" : "+v"(acc[i][j]) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)));
+                }
+        }
+    }
+    __syncthreads();                                                 // every wave is done with the staged words
+    int* part = (int*)lds;                                           // [wave][i * 4 + j][lane]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(wave * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int shared = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) shared += part[(v * 16 + wave * 4 + j) * 64 + lane];
+        if (fin_tot[j] < 0) continue;
+        const double val = lut ? lut[fin_tot[j] * sh_dim + shared] : pc_set_value<METRIC>(shared, fin_tot[j], as_distance);
+        out[pc_out_index(d, sh, fin_s[j], fin_t[j], fin_k[j], condensed)] = val;
+    }
+}
+
+// live 64x64 tiles below which the popcount kernel switches to the word-split 32x32 kernel (measured, jc device time, 64-tile vs
+// word-split: N = 1,000 26.7 / 18.8 us, 2,000 53.6 / 35.8, 3,000 74.6 / 69.0, 5,000 157 / 167: gpurun_out r03_popc_exp2 -> profiles/)
+#define PC_SMALL_GRID_TILES 1536
+
 int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed,
-                       double* lut, int sh_dim, int tot_dim, hipStream_t st) {
+                       double* lut, bool build_lut, int sh_dim, int tot_dim, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
-    dim3 grid(pc_tile_grid((d.N + PT - 1) / PT, (sh.nown + PT - 1) / PT));
-    if (lut) {
+    if (lut && build_lut) {
         const int n = sh_dim * tot_dim;
         if (metric == PC_GCS) hipLaunchKernelGGL(k_set_lut<PC_GCS>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
         else hipLaunchKernelGGL(k_set_lut<PC_JC>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
     }
-    if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
-    else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+    const int64_t tiles64 = (int64_t)((d.N + 63) / 64) * ((sh.nown + 63) / 64);
+    static const int force = getenv("PC_POPC_TILE") ? atoi(getenv("PC_POPC_TILE")) : 0;    // tuning knob: 32 / 64
+    const bool small = force ? force == 32 : tiles64 / 2 < PC_SMALL_GRID_TILES;             // about half of the tiles are live
+    if (small) {
+        dim3 grid(pc_tile_grid((d.N + 31) / 32, (sh.nown + 31) / 32));
+        if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc_ksplit<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+        else hipLaunchKernelGGL(k_set_popc_ksplit<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+    } else {
+        dim3 grid(pc_tile_grid((d.N + 63) / 64, (sh.nown + 63) / 64));
+        if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+        else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_set_popc launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
@@ -383,6 +498,7 @@ __global__ __launch_bounds__(256) void k_walk(PcDev d, PcShard sh, PcWalkArgs a)
         for (int m = 0; m < 4; ++m) if (ok[m]) {
             if (a.na) a.na[sh.lbase[kk[m]] + ss[m]] = acc[m].k;
             if (a.cost_t && acc[m].den) atomicAdd(&a.cost_t[tt[m]], (unsigned long long)acc[m].den);
+            if (a.aln_t && acc[m].k) atomicAdd(&a.aln_t[tt[m]], (unsigned long long)acc[m].k);
             nal += acc[m].k;
         }
         for (int o = 32; o > 0; o >>= 1) {

@@ -6,6 +6,7 @@ library is missing or a call fails, the error is raised, never papered over.
 
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -33,18 +34,20 @@ class PcPacked(ctypes.Structure):
 class PcStats(ctypes.Structure):
     _fields_ = [("n_pairs", ctypes.c_int64), ("n_alignments", ctypes.c_int64), ("n_cells", ctypes.c_int64),
                 ("n_tasks", ctypes.c_int64), ("n_residue_bytes", ctypes.c_int64),
-                ("n_align_launches", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_align_launches", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
                 ("ms_total", ctypes.c_float), ("ms_plan", ctypes.c_float), ("ms_align", ctypes.c_float),
                 ("ms_reduce", ctypes.c_float), ("n_distinct_alignments", ctypes.c_int64), ("n_distinct_cells", ctypes.c_int64)]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs",
-           "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev"]
+           "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev", "pc_upload_sets", "pc_upload_residues", "pc_set_plan_budget", "pc_chunk_plan",
+           "pc_variant_width"]
+NEEDS_RESIDUES = ("aai", "peq", "aai_ppos")
 
 _lib = None
 
@@ -75,6 +78,11 @@ def load():
     L.pc_ctx_destroy.argtypes = [vp]
     L.pc_ctx_destroy.restype = None
     L.pc_upload.argtypes = [vp, ctypes.POINTER(PcPacked)]
+    L.pc_upload_sets.argtypes = [vp, ctypes.POINTER(PcPacked)]
+    L.pc_upload_residues.argtypes = [vp, ctypes.POINTER(PcPacked)]
+    L.pc_set_plan_budget.argtypes = [vp, ctypes.c_int64]
+    L.pc_chunk_plan.argtypes = [_u64p, ctypes.c_int, ctypes.c_uint64, _i32p, ctypes.c_int]
+    L.pc_variant_width.argtypes = [ctypes.c_int]
     L.pc_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.pc_set_shard_balanced.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.pc_shard_pairs.argtypes = [vp]
@@ -105,6 +113,44 @@ def _ptr(arr, typ):
     return arr.ctypes.data_as(typ)
 
 
+class BorrowedArray(np.ndarray):
+    """Result of ``Context.fill(borrow=True)``: a read-only view of page-locked memory the context owns.  The view keeps
+    the context alive (so the memory is not freed behind it by garbage collection), and once the loan has ended -- the
+    next fill or upload on the context, or its ``close()`` -- indexing it or converting it raises instead of reading
+    recycled memory.  ``x.copy()`` while the loan lasts gives an ordinary array."""
+
+    _owner = None
+    _live = True
+
+    def _begin_loan(self, owner):
+        self._owner, self._live = owner, True
+
+    def _end_loan(self):
+        self._live, self._owner = False, None
+
+    def __array_finalize__(self, obj):
+        if isinstance(obj, BorrowedArray):          # slices of a loan share its fate through the root object
+            self._root = getattr(obj, "_root", obj)
+
+    def _check_loan(self):
+        if not getattr(self, "_root", self)._live:
+            raise HipLibraryError("this array was lent by Context.fill(borrow=True) and the loan has ended (a later fill / "
+                                  "upload / close on the context recycled its memory); copy it while it is valid")
+
+    def __getitem__(self, item):
+        self._check_loan()
+        return super().__getitem__(item)
+
+    def __array__(self, dtype=None, copy=None):
+        self._check_loan()
+        out = self.view(np.ndarray)
+        return out.astype(dtype) if dtype is not None and dtype != out.dtype else (out.copy() if copy else out)
+
+    def copy(self, order="C"):
+        self._check_loan()
+        return np.array(self.view(np.ndarray), order=order, copy=True)
+
+
 class Context:
     """One GPU.  ``upload`` once, then ``fill`` any of the six metrics."""
 
@@ -120,6 +166,7 @@ class Context:
             raise HipLibraryError(f"libphamclust_hip: status {rc}: {self._lib.pc_last_error().decode()}")
 
     def close(self):
+        self._invalidate_loans()
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.pc_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -137,16 +184,46 @@ class Context:
             pass
 
     # -- data ------------------------------------------------------------------
-    def upload(self, packed):
+    @staticmethod
+    def _struct(packed):
+        return PcPacked(packed.n_genomes, packed.n_phams, packed.words_per_row, 0,
+                        _ptr(packed.bitmap, _u64p), _ptr(packed.nph, _i32p), _ptr(packed.ngen, _i32p),
+                        _ptr(packed.tlen, _i64p), _ptr(packed.gene_off, _i64p), _ptr(packed.gene_pham, _i32p),
+                        _ptr(packed.seq_off, _i64p), _ptr(packed.residues, _u8p))
+
+    def upload(self, packed, residues=True):
+        """Genomes to HBM.  ``residues=False`` uploads only what gcs / jc / pocp / af read (pham sets, gene counts,
+        translation lengths: metrics.py:26-157) -- about a tenth of the time; the residues follow by themselves the first
+        time an aai / peq fill (or ``align_pairs``) asks for them, from the packed object this context keeps alive."""
         packed.validate()
-        s = PcPacked(packed.n_genomes, packed.n_phams, packed.words_per_row, 0,
-                     _ptr(packed.bitmap, _u64p), _ptr(packed.nph, _i32p), _ptr(packed.ngen, _i32p),
-                     _ptr(packed.tlen, _i64p), _ptr(packed.gene_off, _i64p), _ptr(packed.gene_pham, _i32p),
-                     _ptr(packed.seq_off, _i64p), _ptr(packed.residues, _u8p))
-        self._check(self._lib.pc_upload(self._h, ctypes.byref(s)))
+        s = self._struct(packed)
+        self._invalidate_loans()
+        self._check((self._lib.pc_upload if residues else self._lib.pc_upload_sets)(self._h, ctypes.byref(s)))
         self._packed = packed
+        self._residues = bool(residues)
         self._shard = (0, 1, False)               # pc_upload resets the shard to "everything"
         return self
+
+    def ensure_residues(self):
+        if not getattr(self, "_residues", False):
+            if self._packed is None:
+                raise HipLibraryError("no genomes uploaded")
+            s = self._struct(self._packed)
+            self._check(self._lib.pc_upload_residues(self._h, ctypes.byref(s)))
+            self._residues = True
+
+    def set_plan_budget(self, n_bytes):
+        """HBM one chunk of an aai / peq fill's plan may take (0 = automatic); fills above it run in chunks, same values."""
+        self._check(self._lib.pc_set_plan_budget(self._h, int(n_bytes)))
+
+    # a borrowed result (fill(borrow=True)) is a view of pinned memory the CONTEXT owns and recycles: every array lent out
+    # is remembered weakly and told when its loan ends (BorrowedArray)
+    def _invalidate_loans(self):
+        for ref in getattr(self, "_loans", []):
+            arr = ref()
+            if arr is not None:
+                arr._end_loan()
+        self._loans = []
 
     @property
     def n_genomes(self):
@@ -190,11 +267,16 @@ class Context:
         memory the context owns (no pageable staging: the D2H copy runs at PCIe speed); the view is only good until the
         next fill or upload on this context -- copy it, or consume it at once as matrix_de_novo does."""
         stats = PcStats()
+        if metric in NEEDS_RESIDUES:
+            self.ensure_residues()
+        self._invalidate_loans()
         if borrow:
             ptr = _f64p()
             self._check(self._lib.pc_fill_borrow(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.byref(ptr), ctypes.byref(stats)))
-            out = np.ctypeslib.as_array(ptr, shape=(max(self.n_pairs, 1),))[:self.n_pairs]
+            out = np.ctypeslib.as_array(ptr, shape=(max(self.n_pairs, 1),))[:self.n_pairs].view(BorrowedArray)
             out.flags.writeable = False
+            out._begin_loan(self)
+            self._loans.append(weakref.ref(out))
             return (out, stats.as_dict()) if want_stats else out
         out = np.empty(max(self.n_pairs, 0), dtype=np.float64)
         buf = out if out.size else np.zeros(1)
@@ -204,12 +286,16 @@ class Context:
 
     def fill_dev(self, metric, as_distance, out_ptr, stream=None, want_stats=True):
         stats = PcStats()
+        if metric in NEEDS_RESIDUES:
+            self.ensure_residues()
         self._check(self._lib.pc_fill_dev(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.c_void_p(out_ptr),
                                           ctypes.c_void_p(stream or 0), ctypes.byref(stats) if want_stats else None))
         return stats.as_dict() if want_stats else None
 
     def fill_shard_dev(self, metric, as_distance, shard_ptr, stream=None, want_stats=True):
         stats = PcStats()
+        if metric in NEEDS_RESIDUES:
+            self.ensure_residues()
         self._check(self._lib.pc_fill_shard_dev(self._h, METRIC_IDS[metric], int(bool(as_distance)),
                                                 ctypes.c_void_p(shard_ptr), ctypes.c_void_p(stream or 0),
                                                 ctypes.byref(stats) if want_stats else None))
@@ -223,6 +309,7 @@ class Context:
     def plan_dev(self, metric, stream=None):
         """Plan the whole (unsharded) aai / peq fill; stats["n_distinct_alignments"] is the length of the result array."""
         stats = PcStats()
+        self.ensure_residues()
         self._check(self._lib.pc_plan_dev(self._h, METRIC_IDS[metric], ctypes.c_void_p(stream or 0), ctypes.byref(stats)))
         return stats.as_dict()
 
@@ -239,6 +326,7 @@ class Context:
 
     # -- test hooks --------------------------------------------------------------
     def align_pairs(self, a_gene, b_gene, variant=0):
+        self.ensure_residues()
         a = np.ascontiguousarray(a_gene, dtype=np.int32)
         b = np.ascontiguousarray(b_gene, dtype=np.int32)
         n = a.shape[0]
@@ -254,8 +342,23 @@ class Context:
     def tie_rule(self):
         return int(self._lib.pc_get_tie_rule(self._h))
 
+    @staticmethod
+    def variant_width(lb):
+        """Columns per lane of the systolic variant chosen for a column gene of ``lb`` residues (0: general kernel)."""
+        return int(load().pc_variant_width(int(lb)))
+
     def last_align_ms(self):
         return float(self._lib.pc_last_align_ms(self._h))
+
+    @staticmethod
+    def chunk_plan(counts, max_per_chunk):
+        """The chunking rule of memory-bounded fills (host arithmetic in the library; no GPU): range starts + [n]."""
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        cuts = np.zeros(counts.shape[0] + 2, dtype=np.int32)
+        n = load().pc_chunk_plan(_ptr(counts, _u64p), counts.shape[0], int(max_per_chunk), _ptr(cuts, _i32p), cuts.shape[0])
+        if n < 0:
+            raise HipLibraryError(load().pc_last_error().decode())
+        return cuts[:n + 1]
 
     def round6(self, values):
         v = np.ascontiguousarray(values, dtype=np.float64)

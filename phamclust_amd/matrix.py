@@ -359,7 +359,8 @@ def matrix_de_novo(genomes, func, cpus, as_distance=True):
         packed = _packed_of(genomes)
         t1 = time.perf_counter()
         ctx = get_context()
-        ctx.upload(packed)
+        # gcs / jc / pocp / af never read a residue (metrics.py:26-157): their upload skips the residue stage
+        ctx.upload(packed, residues=metric in ("aai", "peq"))
         t2 = time.perf_counter()
         if world > 1:
             condensed, stats = distributed.fill_condensed(ctx, metric, as_distance)

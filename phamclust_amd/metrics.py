@@ -26,7 +26,7 @@ def _pairwise(metric, source, target, as_distance):
                         "matrix_de_novo(genomes, func, cpus) fills a whole matrix in one device pass")
     from phamclust_amd.matrix import get_context
     ctx = get_context()
-    ctx.upload(pack_genomes([source, target]))
+    ctx.upload(pack_genomes([source, target]), residues=metric in ("aai", "peq", "aai_ppos"))
     return float(ctx.fill(metric, as_distance=as_distance)[0])
 
 

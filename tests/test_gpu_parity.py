@@ -938,7 +938,7 @@ def test_certified_alignments_equal_the_unique_statistics(gpu_ctx, native_built,
     range is one point any correct Needleman-Wunsch -- parasail included -- must report it: the kernels must, on every
     such alignment, through the default variant chooser; everywhere else they must stay inside the range."""
     from phamclust_amd.synth import synth_packed
-    from phamclust_amd.csrc_info import variant_width_of_length
+    from phamclust_amd import hip
     O = _oracle()
     if dataset == "small_input":
         packed = small_packed
@@ -962,5 +962,160 @@ def test_certified_alignments_equal_the_unique_statistics(gpu_ctx, native_built,
     assert (count[~cert] > 1).all()
     # the certified set runs through many widths of the default chooser
     lens = (packed.seq_off[1:] - packed.seq_off[:-1])[b[cert]]
-    widths = {variant_width_of_length(int(x)) for x in np.unique(lens)}
+    widths = {hip.Context.variant_width(int(x)) for x in np.unique(lens)}
     assert len(widths) >= (8 if dataset == "synth2000" else 4), sorted(widths)
+
+
+def test_chunked_fill_is_the_unchunked_matrix(gpu_ctx, native_built):
+    """Memory-bounded batching (matrix.py:474-493: the reference never holds more than ~10,000 pairs per CPU in flight).
+    With the plan budget forced tiny the synth(2000,5000) peq fill (BASELINE configs[2]) runs plan -> align -> reduce over
+    >= 5 successive target ranges and reproduces the one-piece matrix bit for bit; so do a sharded fill and aai."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(2000, 5000)
+    gpu_ctx.upload(packed)
+    try:
+        want, st1 = gpu_ctx.fill("peq", want_stats=True)
+        assert st1["n_chunks"] == 1
+        gpu_ctx.set_plan_budget(st1["n_alignments"] * 56 // 6)
+        got, st = gpu_ctx.fill("peq", want_stats=True)
+        assert st["n_chunks"] >= 5, st
+        assert np.array_equal(got, want)
+        assert st["n_alignments"] == st1["n_alignments"] and st["n_cells"] == st1["n_cells"]
+        assert st["n_distinct_alignments"] >= st1["n_distinct_alignments"]      # duplicates merge inside a chunk only
+        assert st["ms_align"] > 0 and st["ms_plan"] > 0
+        # without stats (asynchronous w.r.t. the host except for the plan read-backs), into device memory
+        out = torch.full((packed.n_pairs,), -1.0, dtype=torch.float64, device="cuda:0")
+        gpu_ctx.fill_dev("peq", True, out.data_ptr(), torch.cuda.current_stream().cuda_stream, want_stats=False)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        # a shard of a 3-rank job, chunked, against the same shard unchunked
+        gpu_ctx.set_shard(1, 3, balanced=True)
+        stride = gpu_ctx.shard_stride()
+        a = torch.full((stride,), -1.0, dtype=torch.float64, device="cuda:0")
+        b = torch.full((stride,), -2.0, dtype=torch.float64, device="cuda:0")
+        sa = gpu_ctx.fill_shard_dev("peq", True, a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        gpu_ctx.set_plan_budget(0)
+        sb = gpu_ctx.fill_shard_dev("peq", True, b.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert sa["n_chunks"] >= 2 and sb["n_chunks"] == 1 and torch.equal(a, b)
+        gpu_ctx.set_shard(0, 1)
+        # a budget below one target genome's alignments: one target per chunk, still the same values
+        small = synth_packed(120, 600, seed=9)
+        gpu_ctx.upload(small)
+        want_aai = gpu_ctx.fill("aai")
+        gpu_ctx.set_plan_budget(56)
+        got_aai, st = gpu_ctx.fill("aai", want_stats=True)
+        assert st["n_chunks"] >= 100 and np.array_equal(got_aai, want_aai)
+        # the alignment-sliced route keeps ONE whole plan: a chunk's plan is not accepted in its place
+        with pytest.raises(Exception):
+            gpu_ctx.align_slice_dev(0, 1, a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    finally:
+        gpu_ctx.set_plan_budget(0)
+        gpu_ctx.set_shard(0, 1)
+
+
+def test_out_of_memory_plan_becomes_smaller_chunks(native_built):
+    """A device allocation that fails inside a fill is answered with smaller chunks, not with PC_ERR_HIP.  The failure is
+    injected (PC_FAKE_OOM_ABOVE: allocations above that many bytes fail), so this runs in its own process."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from phamclust_amd import hip
+from phamclust_amd.synth import synth_packed
+from oracle import oracle as O
+pk = synth_packed(400, 2000, seed=3)
+with hip.Context(0) as ctx:
+    ctx.upload(pk)
+    got, st = ctx.fill("peq", want_stats=True)
+    assert st["n_chunks"] >= 2, st
+    assert np.array_equal(got, O.fill(pk, "peq")), "chunked-after-OOM fill differs from the oracle"
+    print("chunks", st["n_chunks"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 20))       # ~0.25 M alignments: the one-piece plan's A * 8-byte buffers are ~2 MB
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "chunks" in run.stdout
+
+
+def test_two_part_upload(gpu_ctx, native_built):
+    """gcs / jc / pocp / af never read a residue (metrics.py:26-157): pc_upload_sets is enough for them; aai / peq at the
+    C-ABI then answer PC_ERR_STATE until pc_upload_residues, which the Python Context calls by itself."""
+    import ctypes
+    from phamclust_amd import hip
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(150, 800, seed=21)
+    gpu_ctx.upload(packed, residues=False)
+    for metric in SET_METRICS:
+        assert np.array_equal(gpu_ctx.fill(metric), O.fill(packed, metric))
+    lib = hip.load()
+    out = np.zeros(packed.n_pairs)
+    rc = lib.pc_fill(gpu_ctx._h, hip.METRIC_IDS["peq"], 1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), None)
+    assert rc == -3 and b"residues" in lib.pc_last_error()
+    gpu_ctx.set_shard(1, 2, balanced=True)                      # the cost-balanced deal needs lengths only
+    assert gpu_ctx.shard_pairs() > 0
+    gpu_ctx.set_shard(0, 1)
+    assert np.array_equal(gpu_ctx.fill("peq"), O.fill(packed, "peq"))          # the Context uploads the residues on demand
+    assert np.array_equal(gpu_ctx.fill("jc"), O.fill(packed, "jc"))
+    # a different packed object of another size is refused by part 2
+    other = synth_packed(40, 300, seed=2)
+    s = gpu_ctx._struct(other)
+    gpu_ctx.upload(packed, residues=False)
+    assert lib.pc_upload_residues(gpu_ctx._h, ctypes.byref(s)) == -1
+
+
+def test_unsynchronised_slice_survives_reupload(gpu_ctx, native_built):
+    """ADVICE r02: pc_plan_dev / pc_align_slice_dev / pc_reduce_dev without stats leave work on the caller's stream; an
+    upload, pc_align_pairs or a second slice on another stream right behind them must wait for it (one "last work" event)."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    a_pk, b_pk = synth_packed(260, 900, seed=51), synth_packed(70, 400, seed=52)
+    want_a, want_b = O.fill(a_pk, "peq"), O.fill(b_pk, "peq")
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        gpu_ctx.upload(a_pk)
+        plan = gpu_ctx.plan_dev("peq", side.cuda_stream)
+        n = plan["n_distinct_alignments"]
+        with torch.cuda.stream(side):
+            res = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda:0")
+            out = torch.full((a_pk.n_pairs,), -1.0, dtype=torch.float64, device="cuda:0")
+        side.synchronize()
+        gpu_ctx.align_slice_dev(0, 1, res.data_ptr(), side.cuda_stream, want_stats=False)        # returns with K4 in flight
+        gpu_ctx.reduce_dev("peq", True, res.data_ptr(), out.data_ptr(), side.cuda_stream)
+        gpu_ctx.upload(b_pk)                                                                     # rewrites codes, tables
+        got_b = gpu_ctx.fill("peq")
+        side.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want_a)
+        assert np.array_equal(got_b, want_b)
+    # the test hook overwrites the plan's buffers: the plan must not survive it
+    gpu_ctx.upload(a_pk)
+    plan = gpu_ctx.plan_dev("peq")
+    gpu_ctx.align_pairs(np.array([0, 1], np.int32), np.array([2, 3], np.int32))
+    res = torch.zeros(max(plan["n_distinct_alignments"], 1), dtype=torch.int64, device="cuda:0")
+    with pytest.raises(Exception, match="pc_plan_dev first"):
+        gpu_ctx.align_slice_dev(0, 1, res.data_ptr())
+
+
+def test_borrowed_result_loan(gpu_ctx, native_built):
+    """ADVICE r02: fill(borrow=True) lends pinned memory the context recycles; the view refuses access once the loan ended."""
+    from phamclust_amd import hip
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(60, 300, seed=5)
+    gpu_ctx.upload(packed)
+    lent = gpu_ctx.fill("jc", borrow=True)
+    kept = lent.copy()
+    assert type(kept) is np.ndarray and kept.shape == (packed.n_pairs,)
+    assert float(lent[0]) == kept[0] and np.asarray(lent).shape == kept.shape
+    again = gpu_ctx.fill("gcs", borrow=True)                    # ends the first loan
+    with pytest.raises(hip.HipLibraryError, match="loan has ended"):
+        lent[0]
+    with pytest.raises(hip.HipLibraryError, match="loan has ended"):
+        np.asarray(lent)
+    assert again[0] >= 0.0
+    gpu_ctx.upload(packed)
+    with pytest.raises(hip.HipLibraryError):
+        again.copy()

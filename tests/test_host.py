@@ -245,6 +245,7 @@ def test_abi_exports_match_header(native_built):
         assert hasattr(lib, name), name
     assert hip.load().pc_version() == int(re.search(r"#define\s+PC_VERSION\s+(\d+)", header).group(1)) >= 110
     assert ctypes.sizeof(hip.PcPacked) == 16 + 8 * 8 and ctypes.sizeof(hip.PcStats) == 5 * 8 + 2 * 4 + 4 * 4 + 2 * 8
+    assert "n_chunks" in hip.PcStats().as_dict()
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
@@ -315,3 +316,34 @@ def test_text_io_c_path_is_byte_identical(native_built, tmp_path):
         finally:
             M._TEXT_LIB = lib
     assert outputs["c"] == outputs["py"]
+
+
+def test_chunk_plan_arithmetic(native_built):
+    """The rule by which a fill that exceeds its memory budget is cut into target ranges (pc_chunk_plan: host arithmetic in
+    the library, no GPU).  Includes a plan of more than 2^31 alignments -- the size at which r02 refused ("shard the job"):
+    every chunk stays below what one plan can index, the chunks tile the targets, and none is empty."""
+    from phamclust_amd import hip
+    rng = np.random.default_rng(5)
+    assert hip.Context.chunk_plan([], 10).tolist() == [0]
+    assert hip.Context.chunk_plan([5, 5, 5, 20, 1, 1, 1], 10).tolist() == [0, 2, 3, 4, 7]
+    assert hip.Context.chunk_plan([0, 0, 0], 1).tolist() == [0, 3]
+    assert hip.Context.chunk_plan([7], 1).tolist() == [0, 1]                   # one target above the budget: its own chunk
+    # synth-like ramp: target t has ~2.7 alignments per pair (s, t), N = 60,000 genomes -> 4.9e9 alignments
+    n = 60000
+    counts = (np.arange(n, dtype=np.float64) * rng.uniform(1.5, 4.0, n)).astype(np.uint64)
+    total = int(counts.sum())
+    assert total > 2 ** 32
+    limit = 2 ** 31 - 2
+    cuts = hip.Context.chunk_plan(counts, limit)
+    assert cuts[0] == 0 and cuts[-1] == n and (np.diff(cuts) > 0).all()
+    sums = np.add.reduceat(counts, cuts[:-1])
+    assert int(sums.sum()) == total and int(sums.max()) <= limit
+    assert len(sums) <= total // limit + 2 + 1                                 # greedy: at most one chunk more than needed, +1 slack
+    # a memory budget: 16 GiB of plan buffers at 56 B per alignment
+    per_chunk = (16 << 30) // 56
+    cuts = hip.Context.chunk_plan(counts, per_chunk)
+    sums = np.add.reduceat(counts, cuts[:-1])
+    assert int(sums.max()) <= per_chunk and len(sums) >= total // per_chunk
+    # uint64 overflow of the running sum is a cut, not a wrap
+    big = np.array([2 ** 63, 2 ** 63, 5], dtype=np.uint64)
+    assert hip.Context.chunk_plan(big, 2 ** 64 - 1).tolist() == [0, 1, 3]
