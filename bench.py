@@ -164,7 +164,7 @@ def main():
     import torch
     import torch.distributed as dist
     from phamclust_amd import build, hip
-    from phamclust_amd.distributed import dist_mode, fill_distributed
+    from phamclust_amd.distributed import dist_mode, fill_distributed, uses_alignment_slices
     from phamclust_amd.synth import synth_packed
 
     # PC_BENCH_BACKEND=gloo rehearses the N>1 flow on a box with fewer GPUs than ranks (ranks share devices, the
@@ -187,9 +187,10 @@ def main():
 
     packed = synth_packed(a.genomes, a.phams)
     ctx = hip.Context(local_rank)
-    ctx.upload(packed)
+    needs_residues = a.metric in ("aai", "peq")
+    ctx.upload(packed, residues=needs_residues)            # gcs / jc / pocp / af never read a residue: part 1 of the upload only
     n_pairs = packed.n_pairs
-    sliced = world > 1 and dist_mode() == "alignments" and a.metric in ("aai", "peq")     # PHAMCLUST_DIST_MODE=alignments
+    sliced = world > 1 and uses_alignment_slices(a.metric)                               # PHAMCLUST_DIST_MODE=alignments
 
     def step():
         if world == 1:
@@ -220,7 +221,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         agg = torch.tensor([[s["n_alignments"], s["n_cells"], s["n_residue_bytes"], s["n_tasks"], s["ms_align"] * 1e3,
-                             s["ms_total"] * 1e3, s["n_distinct_alignments"], s["n_distinct_cells"]] for s in stats],
+                             s["ms_total"] * 1e3, s["n_distinct_alignments"], s["n_distinct_cells"],
+                             s["ms_plan"] * 1e3, s["ms_reduce"] * 1e3, s.get("ms_exchange", 0.0) * 1e3, s.get("shard_pairs", 0),
+                             s["n_chunks"]] for s in stats],
                            dtype=torch.float64, device="cuda")
         agg_sum = agg.clone(); dist.all_reduce(agg_sum, op=dist.ReduceOp.SUM)
         agg_max = agg.clone(); dist.all_reduce(agg_max, op=dist.ReduceOp.MAX)
@@ -247,12 +250,29 @@ def main():
         ms_align = float(agg_max[:, 4].mean()) / 1e3          # slowest rank's alignment time per step
         ms_dev = float(agg_max[:, 5].mean()) / 1e3
         align_span = [float(agg_min[:, 4].mean()) / 1e3, float(agg_max[:, 4].mean()) / 1e3]
+        # where a multi-GPU step's time goes: per-rank stages as max over ranks (mean over steps), the exchange as rank 0
+        # sees it (it ends when the slowest rank's data has arrived: it contains the wait for that rank), and the root-only
+        # stages (assembly of the gathered shards, or the matrix build of the alignment-sliced route)
+        root_ms = lambda key: sum(s.get(key, 0.0) for s in stats) / len(stats)
+        stage_multi = {"plan_max_over_ranks": float(agg_max[:, 8].mean()) / 1e3, "align_max_over_ranks": float(agg_max[:, 4].mean()) / 1e3,
+                       "align_min_over_ranks": float(agg_min[:, 4].mean()) / 1e3,
+                       "reduce_max_over_ranks": float(agg_max[:, 9].mean()) / 1e3,
+                       "device_total_max_over_ranks": float(agg_max[:, 5].mean()) / 1e3,
+                       "exchange_rank0": root_ms("ms_exchange"), "exchange_max_over_ranks": float(agg_max[:, 10].mean()) / 1e3,
+                       "exchange": "one RCCL reduce of the alignment results" if sliced else "one RCCL gather of the matrix shards",
+                       "exchange_bytes": int(stats[-1].get("exchange_bytes", 0)),
+                       "assemble_rank0": root_ms("ms_root_reduce" if sliced else "ms_assemble"),
+                       "clock": "HIP events on the stream the work runs on" if backend == "nccl" else "host clock (rehearsal transport stages through host memory)"}
+        shard_span = {"pairs_min_max": [int(agg_min[-1, 11]), int(agg_max[-1, 11])], "cells_min_max": [int(agg_min[-1, 1]), int(agg_max[-1, 1])],
+                      "distinct_cells_min_max": [int(agg_min[-1, 7]), int(agg_max[-1, 7])], "chunks_max": int(agg_max[-1, 12])}
 
     line = {
         "metric": "genome-pairs/sec", "value": value, "unit": "genome-pairs/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill",
+        "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill; `value` = fills with the genomes resident in "
+                               f"HBM and the matrix left in HBM (upload and D2H excluded: see value_wall)",
+                   "dist_mode": (dist_mode() if a.metric in ("aai", "peq") else "pairs") if world > 1 else None,
                    "n_genomes": a.genomes, "n_phams": packed.n_phams, "metric_selector": a.metric, "genome_pairs": n_pairs,
                    "n_genes": packed.n_genes, "n_residues": int(packed.residues.size),
                    "parallelism": (f"alignments sliced over {world} GPUs (every rank plans the whole fill) + 1 RCCL reduce of their results + matrix on rank 0"
@@ -314,6 +334,10 @@ def main():
     line["device_ms_per_fill"] = ms_dev
     if world == 1:
         line["stage_ms"] = {k: sum(s[k] for s in stats) / len(stats) for k in ("ms_plan", "ms_align", "ms_reduce")}
+        line["n_chunks"] = stats[-1]["n_chunks"]
+    else:
+        line["stage_ms"] = stage_multi
+        line["shards"] = shard_span
 
     if a.verify_pairs > 0 and n_pairs > 0:
         # sampled check of the assembled matrix against the oracle (random pairs over the whole triangle)
@@ -336,13 +360,15 @@ def main():
         for _ in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ctx.upload(packed)
+            ctx.upload(packed, residues=needs_residues)
             t1 = time.perf_counter()
             host = ctx.fill(a.metric, True, borrow=True)
             t2 = time.perf_counter()
         line["wall_ms_incl_upload_d2h"] = (t2 - t0) * 1e3
         line["wall_breakdown_ms"] = {"upload": (t1 - t0) * 1e3, "kernels_plus_d2h_to_pinned_host": (t2 - t1) * 1e3}
         line["pairs_per_s_incl_upload_d2h"] = n_pairs / (t2 - t0) if n_pairs else 0.0
+        # SURVEY 8(d)'s figure for one matrix, host clock: upload + kernels + D2H of the condensed vector
+        line["value_wall"] = line["pairs_per_s_incl_upload_d2h"]
         assert host.shape[0] == n_pairs
     if world == 1 and a.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(packed, a.metric, a.cpu_seconds)

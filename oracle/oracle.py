@@ -36,8 +36,18 @@ class _Packed(ctypes.Structure):
                 ("gene_off", _i64p), ("gene_pham", _i32p), ("seq_off", _i64p), ("residues", _u8p)]
 
 
+def _lib_path():
+    """libpc_oracle.so next to its sources, or the AddressSanitizer + UBSan twin under oracle/asan/ when
+    PHAMCLUST_NATIVE_VARIANT=asan (built by `python -m phamclust_amd.build --asan`; tests/test_sanitized.py)."""
+    if os.environ.get("PHAMCLUST_NATIVE_VARIANT") == "asan":
+        return os.path.join(_HERE, "asan", "libpc_oracle.so")
+    return _LIB_PATH
+
+
 def build(force=False):
     """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
+    if os.environ.get("PHAMCLUST_NATIVE_VARIANT") == "asan":
+        return _lib_path()
     newest = max(os.path.getmtime(os.path.join(_HERE, name)) for name in ("pc_oracle.c", "pc_cooptimal.c", "Makefile"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpc_oracle.so"], stdout=subprocess.DEVNULL)
@@ -51,7 +61,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = ctypes.CDLL(_LIB_PATH)
+        L = ctypes.CDLL(_lib_path())
         L.pco_nw_stats.argtypes = [_u8p, ctypes.c_int, _u8p, ctypes.c_int, _i32p, _i32p, _i32p]
         L.pco_nw_traceback.argtypes = [_u8p, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_char_p,
                                        ctypes.c_char_p, ctypes.c_char_p, _i32p]

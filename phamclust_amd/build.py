@@ -4,6 +4,12 @@
 * ``csrc/libpc_synth.so``       gcc, the synthetic-data generator
 * ``csrc/libpc_pack.so``        gcc, the TSV loader/packer
 The built files stay next to their sources so that they travel with the tree.
+
+``python -m phamclust_amd.build --asan`` builds the HOST libraries a second time, under ``csrc/asan/`` (and the oracle
+under ``oracle/asan/``), with ``-fsanitize=address,undefined``; ``PHAMCLUST_NATIVE_VARIANT=asan`` makes the package (and
+the oracle) load those instead.  GPU AddressSanitizer is not available on the pool: sanitizers cover the CPU code --
+the TSV loader / formatter / parser that read user files and write into caller buffers, the generator, the checker.
+tests/test_sanitized.py runs them (LD_PRELOAD=libasan) over the loader tests and a small fuzz.
 """
 
 import os
@@ -76,9 +82,45 @@ def build_pack(force=False, verbose=False):
     return PACK_LIB
 
 
+ASAN_FLAGS = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+
+
+def native_path(name):
+    """Where csrc/<name> is loaded from: next to the sources, or the sanitized twin under csrc/asan/ when
+    PHAMCLUST_NATIVE_VARIANT=asan (tests/test_sanitized.py)."""
+    if os.environ.get("PHAMCLUST_NATIVE_VARIANT") == "asan":
+        return os.path.join(CSRC, "asan", name)
+    return os.path.join(CSRC, name)
+
+
+def build_asan(force=False, verbose=False):
+    """libpc_pack.so, libpc_synth.so (csrc/asan/) and libpc_oracle.so (oracle/asan/) under AddressSanitizer + UBSan."""
+    repo = os.path.dirname(os.path.dirname(CSRC))
+    out_dir = os.path.join(CSRC, "asan")
+    ora_dir = os.path.join(repo, "oracle", "asan")
+    os.makedirs(out_dir, exist_ok=True)
+    os.makedirs(ora_dir, exist_ok=True)
+    jobs = [(os.path.join(out_dir, "libpc_pack.so"), [os.path.join(CSRC, "pc_pack.c")], []),
+            (os.path.join(out_dir, "libpc_synth.so"), [os.path.join(CSRC, "pc_synth.c")], []),
+            (os.path.join(ora_dir, "libpc_oracle.so"), [os.path.join(repo, "oracle", "pc_oracle.c"), os.path.join(repo, "oracle", "pc_cooptimal.c")],
+             ["-fopenmp", "-ffp-contract=off"])]
+    built = []
+    for target, sources, extra in jobs:
+        if force or _stale(target, sources):
+            cmd = ["gcc"] + ASAN_FLAGS + extra + ["-fPIC", "-shared", "-o", target] + sources + ["-lm"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        built.append(target)
+    return built
+
+
 def build_all(force=False, verbose=False):
     return build_hip(force, verbose), build_synth(force, verbose), build_pack(force, verbose)
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, verbose=True)
+    if "--asan" in sys.argv:
+        build_asan(force="--force" in sys.argv, verbose=True)
+    else:
+        build_all(force="--force" in sys.argv, verbose=True)

@@ -80,6 +80,53 @@ def dist_mode():
     return mode
 
 
+ALIGNED_METRICS = ("aai", "peq", "aai_ppos")
+
+
+def uses_alignment_slices(metric, mode=None):
+    """True when a multi-rank fill of ``metric`` goes down the alignment-sliced route (one helper for fill_distributed and
+    for bench.py's bookkeeping: every rank of that route reports the WHOLE job's counts, not its share)."""
+    return (mode or dist_mode()) == "alignments" and metric in ALIGNED_METRICS
+
+
+class _StageClock:
+    """HIP-event (or, for host-staged rehearsal transports, host-clock) time of the exchange steps on this rank."""
+
+    def __init__(self, device, on_device):
+        import torch
+        self.torch, self.device, self.on_device = torch, device, on_device
+        self.ms = {}
+
+    def __call__(self, name):
+        return _Stage(self, name)
+
+
+class _Stage:
+    def __init__(self, clock, name):
+        self.c, self.name = clock, name
+
+    def __enter__(self):
+        import time
+        torch = self.c.torch
+        if self.c.on_device:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.c.device))
+        else:
+            torch.cuda.synchronize(self.c.device)
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        torch = self.c.torch
+        if self.c.on_device:
+            self.b.record(torch.cuda.current_stream(self.c.device))
+            self.b.synchronize()
+            self.c.ms[self.name] = self.a.elapsed_time(self.b)
+        else:
+            torch.cuda.synchronize(self.c.device)
+            self.c.ms[self.name] = (time.perf_counter() - self.t0) * 1e3
+
+
 def fill_distributed_alignments(ctx, metric, as_distance=True, group=None):
     """aai / peq over the job's ranks by slicing the ALIGNMENTS (see dist_mode).  Same contract as fill_distributed:
     (condensed f64 CUDA tensor on rank 0 | None elsewhere, stats of this rank's plan + slice)."""
@@ -95,18 +142,29 @@ def fill_distributed_alignments(ctx, metric, as_distance=True, group=None):
     res = torch.empty(max(n, 1), dtype=torch.int64, device=device)       # (n_ident, aln_len) per distinct alignment
     stats = ctx.align_slice_dev(rank, world, res.data_ptr(), stream)
     stats["ms_plan"] = plan["ms_plan"]
+    stats["ms_total"] = plan["ms_plan"] + stats["ms_align"]             # what THIS rank spent on the device (root: + ms_root_reduce)
+    stats["dist_mode"] = "alignments"
+    gloo = world > 1 and dist.get_backend(group) == "gloo"
+    clock = _StageClock(device, on_device=not gloo)
     if world > 1:
-        if dist.get_backend(group) == "gloo":                             # rehearsal transport: staged through host memory
-            host = res.cpu()
-            dist.reduce(host, dst=root, op=dist.ReduceOp.SUM, group=group)
-            if rank == 0:
-                res.copy_(host)
-        else:
-            dist.reduce(res, dst=root, op=dist.ReduceOp.SUM, group=group)  # exactly one rank holds a non-zero entry
+        with clock("ms_exchange"):
+            if gloo:                                                      # rehearsal transport: staged through host memory
+                host = res.cpu()
+                dist.reduce(host, dst=root, op=dist.ReduceOp.SUM, group=group)
+                if rank == 0:
+                    res.copy_(host)
+            else:
+                dist.reduce(res, dst=root, op=dist.ReduceOp.SUM, group=group)  # exactly one rank holds a non-zero entry
+    stats.update(clock.ms)
+    stats["exchange_bytes"] = int(res.numel()) * 8
     if rank != 0:
         return None, stats
     out = torch.empty(max(ctx.n_pairs, 1), dtype=torch.float64, device=device)
-    ctx.reduce_dev(metric, as_distance, res.data_ptr(), out.data_ptr(), stream)
+    with clock("ms_root_reduce"):
+        ctx.reduce_dev(metric, as_distance, res.data_ptr(), out.data_ptr(), stream)
+    stats.update(clock.ms)
+    stats["ms_reduce"] = clock.ms["ms_root_reduce"]
+    stats["ms_total"] += clock.ms["ms_root_reduce"]
     return out[:ctx.n_pairs], stats
 
 
@@ -118,7 +176,7 @@ def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True, m
     above describe.  Returns (condensed f64 CUDA tensor on rank 0 | None elsewhere, stats of this rank)."""
     import torch
     import torch.distributed as dist
-    if (mode or dist_mode()) == "alignments" and metric in ("aai", "peq", "aai_ppos"):
+    if uses_alignment_slices(metric, mode):
         return fill_distributed_alignments(ctx, metric, as_distance, group)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     root = dist.get_global_rank(group, 0) if group is not None else 0      # dist.gather's dst is a GLOBAL rank
@@ -128,21 +186,31 @@ def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True, m
     stream = torch.cuda.current_stream(device).cuda_stream                 # torch's "current device" happens to be
     shard = torch.empty(max(stride, 1), dtype=torch.float64, device=device)
     stats = ctx.fill_shard_dev(metric, as_distance, shard.data_ptr(), stream)
+    stats["dist_mode"] = "pairs"
+    stats["shard_pairs"] = ctx.shard_pairs()
+    gloo = world > 1 and dist.get_backend(group) == "gloo"
+    clock = _StageClock(device, on_device=not gloo)
     if world == 1:
         gathered = shard
-    elif dist.get_backend(group) == "gloo":
-        # rehearsal transport (several ranks sharing one GPU, or no RCCL): same shard / gather / assembly, staged
-        # through host memory because gloo gathers CPU tensors only
-        host = torch.empty(world * max(stride, 1), dtype=torch.float64) if rank == 0 else None
-        dist.gather(shard.cpu(), list(host.chunk(world)) if rank == 0 else None, dst=root, group=group)
-        gathered = host.to(device) if rank == 0 else None
     else:
-        gathered = torch.empty(world * max(stride, 1), dtype=torch.float64, device=device) if rank == 0 else None
-        dist.gather(shard, list(gathered.chunk(world)) if rank == 0 else None, dst=root, group=group)
+        with clock("ms_exchange"):
+            if gloo:
+                # rehearsal transport (several ranks sharing one GPU, or no RCCL): same shard / gather / assembly, staged
+                # through host memory because gloo gathers CPU tensors only
+                host = torch.empty(world * max(stride, 1), dtype=torch.float64) if rank == 0 else None
+                dist.gather(shard.cpu(), list(host.chunk(world)) if rank == 0 else None, dst=root, group=group)
+                gathered = host.to(device) if rank == 0 else None
+            else:
+                gathered = torch.empty(world * max(stride, 1), dtype=torch.float64, device=device) if rank == 0 else None
+                dist.gather(shard, list(gathered.chunk(world)) if rank == 0 else None, dst=root, group=group)
+    stats.update(clock.ms)
+    stats["exchange_bytes"] = int(max(stride, 1)) * 8 * world
     if rank != 0:
         return None, stats
     out = torch.empty(max(ctx.n_pairs, 1), dtype=torch.float64, device=device)
-    ctx.assemble_dev(gathered.data_ptr(), world, out.data_ptr(), stream)
+    with clock("ms_assemble"):
+        ctx.assemble_dev(gathered.data_ptr(), world, out.data_ptr(), stream)
+    stats.update(clock.ms)
     return out[:ctx.n_pairs], stats
 
 

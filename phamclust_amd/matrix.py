@@ -433,7 +433,8 @@ def _text_lib():
     if _TEXT_LIB is None:
         import ctypes
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpc_pack.so")
+        from phamclust_amd.build import native_path
+        path = native_path("libpc_pack.so")
         try:
             lib = ctypes.CDLL(path)
             lib.pcp_format_row.restype = ctypes.c_int64

@@ -149,7 +149,8 @@ def _pack_lib():
     global _PACK_LIB
     if _PACK_LIB is not None:
         return _PACK_LIB
-    lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpc_pack.so")
+    from phamclust_amd.build import native_path
+    lib_path = native_path("libpc_pack.so")
     if not os.path.exists(lib_path):
         raise RuntimeError(f"{lib_path} is missing - run `python -m phamclust_amd.build` first")
 

@@ -12,7 +12,12 @@ import numpy as np
 
 from phamclust_amd.pack import PackedGenomes, unpack_genomes
 
-_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpc_synth.so")
+
+
+def _lib_path():
+    from phamclust_amd.build import native_path
+    return native_path("libpc_synth.so")
+
 
 
 class _Data(ctypes.Structure):
@@ -28,9 +33,10 @@ def default_seed(n_genomes):
 
 def synth_packed(n_genomes, n_phams=5000, seed=None):
     """Generate synth(N, P, seed) directly in packed form (fast: ~1 s for N=5,000)."""
-    if not os.path.exists(_LIB):
-        raise RuntimeError(f"{_LIB} is missing - run `python -m phamclust_amd.build` first")
-    lib = ctypes.CDLL(_LIB)
+    path = _lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing - run `python -m phamclust_amd.build` first")
+    lib = ctypes.CDLL(path)
     lib.pcs_generate.restype = ctypes.POINTER(_Data)
     lib.pcs_generate.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]
     lib.pcs_free.argtypes = [ctypes.POINTER(_Data)]

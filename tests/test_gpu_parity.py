@@ -838,6 +838,13 @@ def test_bench_two_ranks_rehearsal(native_built):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["genome_pairs"] == 301 * 300 // 2 and "REHEARSAL" in d["config"]["parallelism"]
     assert d["verified"]["bit_exact"] is True and d["roofline"]["n_alignments"] > 0
+    # a multi-GPU line explains itself: per-rank stages (max over ranks), the exchange and the root-only assembly, the shards
+    assert d["config"]["dist_mode"] == "pairs"
+    for key in ("plan_max_over_ranks", "align_max_over_ranks", "reduce_max_over_ranks", "exchange_rank0", "assemble_rank0", "exchange_bytes"):
+        assert key in d["stage_ms"], key
+    assert d["stage_ms"]["align_max_over_ranks"] > 0 and d["stage_ms"]["exchange_rank0"] > 0 and d["stage_ms"]["assemble_rank0"] > 0
+    lo, hi = d["shards"]["pairs_min_max"]
+    assert 0 < lo <= hi and lo + hi == 301 * 300 // 2
 
 
 @pytest.mark.parametrize("world", [1, 3, 8])
@@ -919,6 +926,35 @@ def test_bench_two_ranks_rehearsal_alignment_slices(native_built, mode):
     assert d["n_gpus"] == 2 and "alignments sliced" in d["config"]["parallelism"]
     assert d["verified"]["bit_exact"] is True and d["roofline"]["n_alignments"] > 0
     assert d["roofline"]["n_distinct_alignments"] <= d["roofline"]["n_alignments"]
+    assert d["config"]["dist_mode"] == "alignments" and "reduce" in d["stage_ms"]["exchange"]
+    assert d["stage_ms"]["exchange_rank0"] > 0 and d["stage_ms"]["assemble_rank0"] > 0 and d["stage_ms"]["plan_max_over_ranks"] > 0
+
+
+@pytest.mark.parametrize("mode", ["pairs", "alignments"])
+def test_bench_two_gpus_rccl(native_built, mode):
+    """bench.py --gpus 2 over RCCL (backend nccl, one GPU per rank), both ways of splitting an aai / peq fill: the
+    line is bit-exact against the oracle and carries the stage breakdown.  Needs a box with at least two GPUs."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    from conftest import REPO
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU here: the RCCL transport needs two")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PHAMCLUST_DIST_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PC_BENCH_BACKEND", None)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--genomes", "1000", "--steps", "2",
+                           "--warmup", "1", "--verify-pairs", "5000"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["verified"]["bit_exact"] is True and d["config"]["dist_mode"] == mode
+    assert "REHEARSAL" not in d["config"]["parallelism"] and d["stage_ms"]["exchange_rank0"] > 0
 
 
 def test_graft_entry_smoke(native_built):
