@@ -115,6 +115,7 @@ struct pc_ctx {
     std::vector<int32_t> h_owned;           // this rank's targets, ascending, and
     std::vector<int64_t> h_lbase;           // [nown+1] the shard-local index of pair (0, owned[k]) (host copies of shard.owned / lbase)
     // persistent device arrays
+    DevBuf b_ent_pham, b_ent_off;
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
     DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
@@ -213,7 +214,7 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     PcDeviceGuard guard(c->device);
     if (c->busy && c->ev_last) (void)hipEventSynchronize(c->ev_last);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
+    DevBuf* bufs[] = {&c->b_ent_pham, &c->b_ent_off, &c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
                       &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
@@ -323,8 +324,9 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     const int Wstride = W | 1;
     std::vector<uint64_t> bitmap((size_t)N * Wstride, 0);
     std::vector<uint32_t> rankpre((size_t)N * W);
-    std::vector<int32_t> ent_cnt, ent_len, ent_gene, gene_len(G);
-    ent_cnt.reserve(G); ent_len.reserve(G); ent_gene.reserve(G);
+    std::vector<int32_t> ent_cnt, ent_len, ent_gene, ent_pham, gene_len(G);
+    std::vector<uint32_t> ent_off((size_t)N + 1, 0);
+    ent_cnt.reserve(G); ent_len.reserve(G); ent_gene.reserve(G); ent_pham.reserve(G);
     int maxlen = 0, minlen = G ? 0x7fffffff : 0;
     for (int k = 0; k < G; ++k) {
         const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
@@ -346,9 +348,10 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
             }
             int64_t k2 = k; int64_t ln = 0;
             while (k2 < k1 && g->gene_pham[k2] == p) { ln += gene_len[k2]; ++k2; }
-            ent_cnt.push_back((int32_t)(k2 - k)); ent_len.push_back((int32_t)ln); ent_gene.push_back((int32_t)k);
+            ent_cnt.push_back((int32_t)(k2 - k)); ent_len.push_back((int32_t)ln); ent_gene.push_back((int32_t)k); ent_pham.push_back(p);
             tl += ln; k = k2;
         }
+        ent_off[(size_t)s + 1] = (uint32_t)ent_cnt.size();
         const size_t nent = ent_cnt.size() - ent0;
         size_t bits = 0;
         for (int w = 0; w < W; ++w) { rankpre[(size_t)s * W + w] = (uint32_t)(ent0 + bits); bits += (size_t)__builtin_popcountll(row[w]); }
@@ -361,6 +364,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     std::vector<int64_t> tlen(g->tlen, g->tlen + N);
     if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
         (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
+        (rc = upload_vec(c->b_ent_pham, ent_pham)) || (rc = upload_vec(c->b_ent_off, ent_off)) ||
         (rc = upload_vec(c->b_nph, nph)) || (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)))
         return rc;
     PcDev& d = c->dev;
@@ -369,6 +373,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     d.bitmap = c->b_bitmap.as<uint64_t>(); d.rankpre = c->b_rankpre.as<uint32_t>();
     d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
     d.gene_len = c->b_gene_len.as<int32_t>();
+    d.ent_pham = c->b_ent_pham.as<int32_t>(); d.ent_off = c->b_ent_off.as<uint32_t>();
     d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
@@ -1035,9 +1040,15 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         PC_HIP(hipEventRecord(c->ev[3], st));
         local.n_chunks = 1;
     } else if (metric == PC_POCP || metric == PC_AF) {
-        PcWalkArgs a; memset(&a, 0, sizeof(a));
-        a.out = out; a.as_distance = as_distance; a.condensed = condensed;
-        rc = pc_launch_walk(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, a, st);
+        // small matrices: the sparse tile kernel; large ones: the shared-pham walker (crossover measured at ~3,500 genomes;
+        // PC_SET_KERNEL=walker|sparse forces one for A/B runs)
+        static const char* force = getenv("PC_SET_KERNEL");
+        const bool walker = force ? !strcmp(force, "walker") : (int64_t)d.N * c->shard.nown > (int64_t)3500 * 3500;
+        if (walker) {
+            PcWalkArgs a; memset(&a, 0, sizeof(a));
+            a.out = out; a.as_distance = as_distance; a.condensed = condensed;
+            rc = pc_launch_walk(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, a, st);
+        } else rc = pc_launch_sparse(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, out, as_distance, condensed, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
         local.n_chunks = 1;

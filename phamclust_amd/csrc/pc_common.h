@@ -24,6 +24,8 @@ struct PcDev {
     const int32_t* ent_cnt;           // [E] genes of the genome in that pham
     const int32_t* ent_len;           // [E] their summed length
     const int32_t* ent_gene;          // [E] first gene id (genes of an entry are consecutive)
+    const int32_t* ent_pham;          // [E] pham id (ascending within a genome: the set bits of its bitmap row, in order)
+    const uint32_t* ent_off;          // [N+1] entries of genome g = [ent_off[g], ent_off[g+1])
     const int32_t* gene_len;          // [G]
     const int64_t* gene_off;          // [G] byte offset of the gene's codes (16-byte aligned)
     const uint8_t* codes;             // encoded residues, each gene padded to 16 B with PC_PADCODE
@@ -88,6 +90,7 @@ void pc_set_error(const char* fmt, ...);
 int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed,
                        double* lut, bool build_lut, int sh_dim, int tot_dim, hipStream_t st);
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
+int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st);   // pocp / af
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
 // planning of the alignment batch (pc_plan.hip)

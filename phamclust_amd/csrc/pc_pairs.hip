@@ -23,7 +23,7 @@
 // round(x, 6) exactly as CPython: decimal(x) correctly rounded half-even to 6 places,
 // then the nearest double.  x in [0, 2^20).  x*1e6 = M * 15625 * 2^(e+6) exactly.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ double pc_round6(double x) {
+__device__ __noinline__ double pc_round6_exact(double x) {
     if (!(x > 0.0)) return 0.0;
     unsigned long long bits = (unsigned long long)__double_as_longlong(x);
     int ex = (int)((bits >> 52) & 0x7ff);
@@ -51,6 +51,21 @@ __device__ __forceinline__ double pc_round6(double x) {
         if (gt || (eq && (ip & 1))) ++ip;
     }
     return (double)ip / 1000000.0;
+}
+
+// The same value, usually in a dozen instructions.  y = fl(x * 1e6) is within 2^-33 of the exact product for x < 2, so
+// when y is not within 2^-30 of a half-integer the exact product rounds (half-even or not: it is no tie) to rint(y), and the
+// result is that integer divided by 1e6 -- the very division the exact routine ends with.  Only values that close to a
+// decimal tie (two in a million) take the 128-bit integer route.  Every metric's epilogue runs this once or twice per genome
+// pair; with the exact routine alone it was most of the sparse pocp / af kernel's time.
+__device__ __forceinline__ double pc_round6(double x) {
+    if (!(x > 0.0)) return 0.0;
+    if (x < 2.0) {
+        const double y = x * 1.0e6;
+        const double k = __builtin_rint(y);
+        if (__builtin_fabs(y - k) <= 0.5 - 0x1p-30) return k / 1000000.0;
+    }
+    return pc_round6_exact(x);
 }
 
 __device__ __forceinline__ double pc_finish(double sim, int as_distance) {
@@ -366,6 +381,139 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_set_popc launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// K2 for SMALL matrices: pocp / af as a SPARSE bitset intersection (r03).  Used below ~3,500 genomes, where it beats the
+// shared-pham walker (N = 2,000: 0.122 against 0.184 ms); above, the walker stays (N = 20,000: 5.6 against 7.1 ms --
+// where the time goes: `profiles/r03_c_sparse_tile_experiment.txt`: the divergent per-bit add loops 3.6 ms, mask build + reads
+// 2.9 ms, everything else, fp64 epilogue included, 0.7 ms).
+//
+// A genome holds ~100 of the P = 5,000 phams, a pair shares ~3 of them, and pocp / af need a value per SHARED pham
+// (gene count, summed length: metrics.py:102-103, 135-147).  The walker scans all W words of both bitmap rows per pair
+// and then chases rank table -> entry table for every hit: 2.8 x the popcount kernel, 3.5 % of HBM speed at N = 20,000.
+// Here the work follows the shared phams instead of the words.  One workgroup owns a 32 x 32 tile of pairs and
+//   A. transposes the tile's 32 TARGET bitmap rows into LDS: colmask[p] = which of the 32 targets hold pham p (built
+//      from the targets' entry lists -- the set bits of their rows -- with LDS atomic ORs),
+//   B. lets every entry (p, v) of the 32 SOURCE rows look up colmask[p] and add v into acc[source][target] for each set
+//      bit (LDS atomic adds; 64-bit: value in the low 40 bits, a hit count above them, so "no shared pham" stays
+//      distinguishable from "shared phams of total value 0"),
+//   C. does the same with the roles swapped (colmask over the sources, the targets' entries probe), and
+//   D. finishes each pair: (sum_s + sum_t) / (total_s + total_t), 1 - x, round(., 6) in fp64, one coalesced store.
+// Per pair that is ~2 x 6 entry visits + ~6 atomic adds + the epilogue instead of 79 word scans + the visits.  Phams are
+// processed in chunks of CH (the colmask array is CH words of dynamic LDS), entry ranges of a chunk come from the rank
+// table (rankpre is the entry index at every 64-pham word boundary).  No MFMA: there is no dense contraction, and at 2 %
+// density a dense one would do 50 x the work.
+// ---------------------------------------------------------------------------------
+#define SP_T 32                                                   // tile edge (genomes); masks are one u32
+#define SP_IT 16                                                  // entries a lane loads per batch (8 lanes per row: 128 entries of a row)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sparse_tile(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+    uint32_t* colmask = sp_lds;                                                    // [CH]
+    unsigned long long* acc = (unsigned long long*)(sp_lds + CH);                  // [32 sources][32 targets]  (CH is even: 8-byte aligned)
+    __shared__ int g_s[SP_T], g_t[SP_T];                                           // genome of tile row r, -1: none
+    int tile_x, tile_y;
+    if (!pc_tile_of_block((d.N + SP_T - 1) / SP_T, (sh.nown + SP_T - 1) / SP_T, tile_x, tile_y)) return;
+    const int s0 = tile_x * SP_T, k0 = tile_y * SP_T;
+    const int klast = min(k0 + SP_T, sh.nown) - 1;
+    if (s0 >= pc_owned(sh, klast)) return;
+    if (threadIdx.x < SP_T) {
+        const int s = s0 + threadIdx.x, k = k0 + threadIdx.x;
+        g_s[threadIdx.x] = s < d.N ? s : -1;
+        g_t[threadIdx.x] = k < sh.nown ? pc_owned(sh, k) : -1;
+    }
+    for (int i = threadIdx.x; i < SP_T * SP_T; i += 256) acc[i] = 0ULL;
+    // a row's entries go to 8 consecutive lanes: lane (row = tid >> 3, sub = tid & 7) takes entries sub, sub + 8, ...
+    // Every phase first issues ALL its global loads (SP_IT independent loads per lane and array: one memory latency per
+    // phase, not one per entry -- with the loads inside the loops a tile took 52 of them back to back and the kernel was
+    // slower than the walker), then works on LDS only.
+    const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int32_t* __restrict__ val = MODE == PCW_POCP ? d.ent_cnt : d.ent_len;
+    for (int p0 = 0; p0 < d.Wb * 64; p0 += CH) {
+        const int w0 = p0 >> 6, w1 = min(d.Wb, (p0 + CH) >> 6);
+        __syncthreads();                                                            // g_s, g_t, acc visible / previous chunk done
+        uint32_t ebs = 0, ees = 0, ebt = 0, eet = 0;                                // my rows' entries of this chunk
+        if (g_s[row] >= 0) {
+            ebs = d.rankpre[(int64_t)g_s[row] * d.Wb + w0];
+            ees = w1 < d.Wb ? d.rankpre[(int64_t)g_s[row] * d.Wb + w1] : d.ent_off[g_s[row] + 1];
+        }
+        if (g_t[row] >= 0) {
+            ebt = d.rankpre[(int64_t)g_t[row] * d.Wb + w0];
+            eet = w1 < d.Wb ? d.rankpre[(int64_t)g_t[row] * d.Wb + w1] : d.ent_off[g_t[row] + 1];
+        }
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: masks over the targets, the sources' entries probe; pass 1: the other way round
+            const uint32_t bb = pass == 0 ? ebt : ebs, be = pass == 0 ? eet : ees;  // rows that BUILD the masks
+            const uint32_t qb = pass == 0 ? ebs : ebt, qe = pass == 0 ? ees : eet;  // rows that PROBE them
+            if (pass) __syncthreads();                                              // previous probes done
+            for (int i = threadIdx.x * 4; i < CH; i += 1024) *(uint4*)&colmask[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+            for (uint32_t e0 = bb + sub; e0 < be; e0 += 8 * SP_IT) {
+                int ph[SP_IT];
+#pragma unroll
+                for (int i = 0; i < SP_IT; ++i) ph[i] = e0 + 8 * i < be ? d.ent_pham[e0 + 8 * i] - p0 : -1;
+#pragma unroll
+                for (int i = 0; i < SP_IT; ++i) if (ph[i] >= 0) atomicOr(&colmask[ph[i]], 1u << row);
+            }
+            __syncthreads();
+            for (uint32_t e0 = qb + sub; e0 < qe; e0 += 8 * SP_IT) {
+                int ph[SP_IT]; uint32_t vv[SP_IT], mm[SP_IT];
+#pragma unroll
+                for (int i = 0; i < SP_IT; ++i) {
+                    const bool in = e0 + 8 * i < qe;
+                    ph[i] = in ? d.ent_pham[e0 + 8 * i] - p0 : -1;
+                    vv[i] = in ? (uint32_t)val[e0 + 8 * i] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < SP_IT; ++i) mm[i] = ph[i] >= 0 ? colmask[ph[i]] : 0u;
+#pragma unroll
+                for (int i = 0; i < SP_IT; ++i) {
+                    uint32_t m = mm[i];
+                    const unsigned long long v = (1ULL << 40) | (unsigned long long)vv[i];
+                    while (m) {
+                        const int o = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        atomicAdd(&acc[pass == 0 ? row * SP_T + o : o * SP_T + row], v);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // finish: 1,024 pairs, 4 per thread; consecutive lanes run along the output's contiguous direction
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = threadIdx.x + 256 * q;
+        const int fast = idx & 31, slow = idx >> 5;
+        const int ls = condensed ? slow : fast, lt = condensed ? fast : slow;
+        const int s = g_s[ls], t = g_t[lt];
+        if (s < 0 || t < 0 || s >= t) continue;
+        const unsigned long long a = acc[ls * SP_T + lt];
+        const bool any = (a >> 40) != 0;
+        const long long cons = (long long)(a & ((1ULL << 40) - 1));
+        double sim = 0.0;
+        if (any) {
+            if (MODE == PCW_POCP) sim = (double)cons / (double)(d.ngen[s] + d.ngen[t]);    // metrics.py:104-110
+            else sim = (double)cons / (double)(d.tlen[s] + d.tlen[t]);                      // metrics.py:149-152
+        }
+        out[pc_out_index(d, sh, s, t, k0 + lt, condensed)] = pc_finish(sim, as_distance);
+    }
+}
+
+int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
+    if (sh.nown <= 0 || d.N <= 1) return PC_OK;
+    // colmask chunk: all phams at once while that leaves three workgroups per CU (48 KB each), else 8,192 at a time
+    const int P64 = d.Wb * 64;
+    const int CH = P64 <= 10240 ? P64 : 8192;
+    const size_t lds = (size_t)CH * 4 + (size_t)SP_T * SP_T * 8;
+    dim3 grid(pc_tile_grid((d.N + SP_T - 1) / SP_T, (sh.nown + SP_T - 1) / SP_T)), block(256);
+    if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH);
+    else hipLaunchKernelGGL(k_sparse_tile<PCW_AF>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_sparse_tile launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
 }
 

@@ -1150,7 +1150,7 @@ def test_borrowed_result_loan(gpu_ctx, native_built):
     with pytest.raises(hip.HipLibraryError, match="loan has ended"):
         lent[0]
     with pytest.raises(hip.HipLibraryError, match="loan has ended"):
-        np.asarray(lent)
+        lent.copy()
     assert again[0] >= 0.0
     gpu_ctx.upload(packed)
     with pytest.raises(hip.HipLibraryError):
