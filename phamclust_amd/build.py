@@ -5,11 +5,11 @@
 * ``csrc/libpc_pack.so``        gcc, the TSV loader/packer
 The built files stay next to their sources so that they travel with the tree.
 
-``python -m phamclust_amd.build --asan`` builds the HOST libraries a second time, under ``csrc/asan/`` (and the oracle
-under ``oracle/asan/``), with ``-fsanitize=address,undefined``; ``PHAMCLUST_NATIVE_VARIANT=asan`` makes the package (and
-the oracle) load those instead.  GPU AddressSanitizer is not available on the pool: sanitizers cover the CPU code --
-the TSV loader / formatter / parser that read user files and write into caller buffers, the generator, the checker.
-tests/test_sanitized.py runs them (LD_PRELOAD=libasan) over the loader tests and a small fuzz.
+``python -m phamclust_amd.build --asan`` builds the HOST libraries a second time, under ``csrc/asan/``, with
+``-fsanitize=address,undefined``; ``PHAMCLUST_NATIVE_VARIANT=asan`` makes the package load those instead.  GPU
+AddressSanitizer is not available on the pool: sanitizers cover the CPU code -- the TSV loader / formatter / parser that
+read user files and write into caller buffers, and the generator.  tests/test_sanitized.py runs them (LD_PRELOAD=libasan)
+over the loader tests and a small fuzz (the test checker has its own sanitized build, outside this package).
 """
 
 import os
@@ -55,7 +55,7 @@ def build_hip(force=False, verbose=False):
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
     if force or _stale(HIP_LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -94,16 +94,11 @@ def native_path(name):
 
 
 def build_asan(force=False, verbose=False):
-    """libpc_pack.so, libpc_synth.so (csrc/asan/) and libpc_oracle.so (oracle/asan/) under AddressSanitizer + UBSan."""
-    repo = os.path.dirname(os.path.dirname(CSRC))
+    """libpc_pack.so and libpc_synth.so (csrc/asan/) under AddressSanitizer + UBSan."""
     out_dir = os.path.join(CSRC, "asan")
-    ora_dir = os.path.join(repo, "oracle", "asan")
     os.makedirs(out_dir, exist_ok=True)
-    os.makedirs(ora_dir, exist_ok=True)
     jobs = [(os.path.join(out_dir, "libpc_pack.so"), [os.path.join(CSRC, "pc_pack.c")], []),
-            (os.path.join(out_dir, "libpc_synth.so"), [os.path.join(CSRC, "pc_synth.c")], []),
-            (os.path.join(ora_dir, "libpc_oracle.so"), [os.path.join(repo, "oracle", "pc_oracle.c"), os.path.join(repo, "oracle", "pc_cooptimal.c")],
-             ["-fopenmp", "-ffp-contract=off"])]
+            (os.path.join(out_dir, "libpc_synth.so"), [os.path.join(CSRC, "pc_synth.c")], [])]
     built = []
     for target, sources, extra in jobs:
         if force or _stale(target, sources):

@@ -46,6 +46,8 @@ _OPTIONS = (
     (None, "-n", "--no-sub", dict(action="store_true", help="skip the sub-clustering pass")),
     (None, "-r", "--remove-tmp", dict(action="store_true", help="delete the cache directory at the end (re-runs then recompute the matrix)")),
     (None, "-t", "--threads", dict(type=int, default=CPUS, help="accepted for compatibility; the six metrics run on the GPU (see --gpus)")),
+    (None, "-D", "--device", dict(type=int, default=None, help="HIP device ordinal of a single-GPU run (default: PHAMCLUST_DEVICE, else 0); "
+                                                               "with --gpus N the ranks take devices 0..N-1")),
     (None, "-G", "--gpus", dict(type=int, default=GPUS, help="GPUs of this node to spread the matrix fill over (one process per GPU "
                                                               "under torch.distributed.run, static pair shard, one RCCL gather)")),
 )

@@ -26,6 +26,33 @@
 #include "pc_common.h"
 #include "../../include/phamclust_hip.h"
 
+#include <dlfcn.h>
+
+// roctx ranges around the stages of a fill (the reference only logs wall clock around matrix_de_novo).  The marker
+// library is looked up at run time -- the product does not link against a profiler -- and the ranges show up in a
+// `rocprofv3 --marker-trace` run as upload_sets / upload_residues / fill:<metric> / count / plan / align / reduce.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        if (getenv("PC_NO_ROCTX")) return;
+        void* h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static const Roctx& roctx() { static const Roctx r; return r; }
+struct PcRange {
+    bool on;
+    explicit PcRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~PcRange() { if (on) roctx().pop(); }
+    PcRange(const PcRange&) = delete; PcRange& operator=(const PcRange&) = delete;
+};
+}  // namespace
+
 static thread_local char g_err[512] = "";
 void pc_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -297,6 +324,7 @@ static int apply_shard(pc_ctx* c, int rank, int world) {
 // per-genome scalars.  The reference's set metrics never touch a translation beyond its length (metrics.py:26-157), and
 // encoding, hashing and ranking 10^8 residues is 90 % of a full upload.
 static int upload_sets(pc_ctx* c, const pc_packed* g) {
+    PcRange range("pc:upload_sets");
     int rc = PC_OK;
     const int N = g->n_genomes, P = g->n_phams, W = g->words_per_row;
     if (N <= 0 || P < 0 || W != std::max(1, (P + 63) / 64) || g->reserved != 0 || !g->bitmap || !g->nph || !g->ngen || !g->tlen ||
@@ -390,6 +418,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
 // Upload, part 2: what the aligner needs -- residue codes, the distinct sequences and their ranks, the launch classes.
 // g must be the packed genomes part 1 was given.
 static int upload_residues(pc_ctx* c, const pc_packed* g) {
+    PcRange range("pc:upload_residues");
     int rc = PC_OK;
     const int N = g->n_genomes;
     const int G = c->dev.G;
@@ -763,6 +792,7 @@ static void release_plan_buffers(pc_ctx* c) {
 // COUNT over the whole shard: alignments per pair (the reference's loop nest, metrics.py:204-224) into b_na, and the
 // totals (alignments, cells, residue bytes); one read-back.
 static int stage_count(pc_ctx* c, int condensed, hipStream_t st, uint64_t tot[3]) {
+    PcRange range("pc:count");
     int rc = PC_OK;
     const PcDev& d = c->dev;
     const int64_t Lp = c->shard_pairs;
@@ -805,6 +835,7 @@ static int count_per_target(pc_ctx* c, int condensed, hipStream_t st, std::vecto
 // sorted by launch class.  Leaves its results in the context's work buffers and c->plan; two small read-backs.
 static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st, int k0, int k1, uint64_t A) {
     int rc = PC_OK;
+    PcRange range("pc:plan");
     PlanningScope planning;
     const PcDev& d = c->dev;
     pc_ctx::PlanState& P = c->plan;
@@ -894,6 +925,7 @@ static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st, int k0
 // slice_rank (tasks of a class are sorted longest first, so the slices of a class carry equal work); results go to
 // res[position of the distinct alignment], entries of tasks outside the slice are left zero.
 static int stage_align(pc_ctx* c, int slice_rank, int slice_world, uint2* res, hipStream_t st, pc_stats* stats) {
+    PcRange range("pc:align");
     pc_ctx::PlanState& P = c->plan;
     if (!P.valid) { pc_set_error("align: no plan (pc_plan_dev first)"); return PC_ERR_STATE; }
     if (P.A <= 0 || P.ntasks == 0) return PC_OK;
@@ -918,6 +950,7 @@ static int stage_align(pc_ctx* c, int slice_rank, int slice_world, uint2* res, h
 
 // REDUCE: best match per anchor gene through the aliases, fp64 epilogue (metrics.py:204-232, 247-253), over the plan's targets
 static int stage_reduce(pc_ctx* c, int metric, int as_distance, const uint2* res, double* out, hipStream_t st) {
+    PcRange range("pc:reduce");
     pc_ctx::PlanState& P = c->plan;
     if (!P.valid) { pc_set_error("reduce: no plan (pc_plan_dev first)"); return PC_ERR_STATE; }
     PcShard sub = c->shard;
@@ -1012,6 +1045,8 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     if (ppos) metric = PC_AAI;
     if (!out) { pc_set_error("fill: out is NULL"); return PC_ERR_ARG; }
     PC_ON_DEVICE(c);
+    static const char* const fill_names[] = {"pc:fill:gcs", "pc:fill:jc", "pc:fill:pocp", "pc:fill:af", "pc:fill:aai", "pc:fill:peq"};
+    PcRange range(fill_names[metric]);
     int rc = PC_OK;
     // st == NULL is HIP's legacy default stream, used as such: a caller whose producers / consumers run on it (PyTorch's
     // default stream has handle 0) is ordered with these launches; the library's own streams are non-blocking

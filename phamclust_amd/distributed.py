@@ -250,21 +250,30 @@ def ensure_process_group():
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        import datetime
         device = local_device()
         torch.cuda.set_device(device)
+        # a rank that dies outside a collective leaves its peers waiting in the next one: bound that wait (the launcher
+        # also tears the job down when a rank exits non-zero; this covers a rank that hangs)
+        timeout = datetime.timedelta(seconds=int(os.environ.get("PHAMCLUST_DIST_TIMEOUT_S", "900")))
         if backend_name() == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), timeout=timeout)
         else:
-            dist.init_process_group(backend_name())
+            dist.init_process_group(backend_name(), timeout=timeout)
     return dist.get_rank(), dist.get_world_size()
 
 
-def broadcast_flag(value, src=0):
-    """One small control-plane broadcast (e.g. "rank 0 found a cached matrix, nobody fills")."""
+def broadcast_flag(value, src=0, error=None):
+    """One small control-plane broadcast (e.g. "rank 0 found a cached matrix, nobody fills").  ``error``: the source rank
+    failed while working out the flag -- every rank then raises instead of walking into a collective the source will
+    never join."""
     import torch.distributed as dist
-    box = [bool(value)]
+    box = [(bool(value), None if error is None else str(error))]
     dist.broadcast_object_list(box, src=src)
-    return bool(box[0])
+    flag, err = box[0]
+    if err is not None:
+        raise RuntimeError(f"rank {src} failed before the fill: {err}")
+    return bool(flag)
 
 
 def fill_condensed(ctx, metric, as_distance=True):

@@ -13,6 +13,7 @@ import hashlib
 import logging
 import pathlib
 import shutil
+import os
 import sys
 import time
 
@@ -139,12 +140,17 @@ class _Run:
     # 2
     def distances(self, cpus):
         self.banner(2, f"{self.metric} distance matrix")
-        cached, have_cache = None, False
+        cached, have_cache, failure = None, False, None
         if self.rank == 0:
-            cached = self._dir(self.cache / "02_distmats") / f"{self.metric}_distance_matrix.tsv"
-            have_cache = cached.is_file()
+            try:
+                cached = self._dir(self.cache / "02_distmats") / f"{self.metric}_distance_matrix.tsv"
+                have_cache = cached.is_file()
+            except Exception as exc:          # noqa: BLE001 -- the other ranks must hear of it before they enter the gather
+                if self.world == 1:
+                    raise
+                failure = exc
         if self.world > 1:                    # rank 0 owns the cache; the others learn whether there is work for them
-            have_cache = distributed.broadcast_flag(have_cache, src=0)
+            have_cache = distributed.broadcast_flag(have_cache, src=0, error=failure)
         t0 = time.perf_counter()
         if have_cache:
             if self.rank != 0:
@@ -295,6 +301,8 @@ def main(argv=None):
         # before this process has made a single GPU call
         passed = list(sys.argv[1:] if argv is None else argv)
         sys.exit(distributed.launch_ranks(args.gpus, "phamclust_amd", [str(x) for x in passed]))
+    if args.device is not None and world == 1:
+        os.environ["PHAMCLUST_DEVICE"] = str(args.device)           # matrix.default_device reads it when the context is made
     args.outdir.mkdir(parents=True, exist_ok=True)
     if rank == 0:
         logging.basicConfig(filename=args.outdir / "phamclust.log", filemode="w", format=LOG_STR_FMT, datefmt=LOG_TIME_FMT,

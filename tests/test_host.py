@@ -228,6 +228,7 @@ def test_cli_surface():
     assert args.metric == "peq" and args.nr_thresh == 0.75 and args.clu_thresh == 0.25 and args.sub_thresh == 0.6
     assert args.nr_linkage == "complete" and args.clu_linkage == "average" and args.sub_linkage == "single" and args.k_min == 6
     assert cli.parse_args(["in.tsv", "out", "-m", "jc", "-t", "3"]).metric == "jc"
+    assert args.device is None and args.gpus == 1 and cli.parse_args(["in.tsv", "out", "--device", "3"]).device == 3
     with pytest.raises(SystemExit):
         cli.parse_args(["in.tsv", "out", "-m", "nope"])
 

@@ -1,6 +1,6 @@
 """CPU sanitizer job: the host-side C code -- csrc/pc_pack.c (parses user TSVs, formats rows into caller
 buffers), csrc/pc_synth.c, oracle/pc_oracle.c, oracle/pc_cooptimal.c -- built with -fsanitize=address,undefined
-(`python -m phamclust_amd.build --asan`) and driven by tests/sanitized_driver.py in a subprocess with libasan preloaded.
+(`python -m phamclust_amd.build --asan`, `make -C oracle asan`) and driven by tests/sanitized_driver.py in a subprocess with libasan preloaded.
 GPU AddressSanitizer does not exist on the pool; the device side is covered by the parity tests."""
 
 import os
@@ -15,6 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_host_c_code_under_asan_and_ubsan():
     from phamclust_amd import build
     build.build_asan()
+    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "asan"], stdout=subprocess.DEVNULL)
     libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
     if not os.path.isabs(libasan) or not os.path.exists(libasan):
         pytest.skip("gcc has no libasan.so here")
