@@ -90,8 +90,8 @@ struct DevBuf {
 };
 
 // fn(begin, end) over [0, n) on up to 16 host threads (upload-time indexing of ~10^8 residues)
-template <class F> void parallel_chunks(int64_t n, F fn) {
-    int nt = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), (n + 4095) / 4096);
+template <class F> void parallel_chunks(int64_t n, F fn, int64_t grain = 4096) {
+    int nt = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), (n + grain - 1) / grain);
     if (nt <= 1) { fn((int64_t)0, n); return; }
     std::vector<std::thread> th;
     const int64_t per = (n + nt - 1) / nt;
@@ -348,44 +348,71 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     c->uploaded = false; c->residues_ready = false; c->target_cost.clear(); c->plan.valid = false;
     PC_HIP(hipStreamSynchronize(c->stream));
 
-    // ---- host-side indices -------------------------------------------------------
+    // ---- host-side indices (on several threads: genomes are independent once every genome knows where its entries start)
     const int Wstride = W | 1;
     std::vector<uint64_t> bitmap((size_t)N * Wstride, 0);
     std::vector<uint32_t> rankpre((size_t)N * W);
-    std::vector<int32_t> ent_cnt, ent_len, ent_gene, ent_pham, gene_len(G);
+    std::vector<int32_t> gene_len(G);
     std::vector<uint32_t> ent_off((size_t)N + 1, 0);
-    ent_cnt.reserve(G); ent_len.reserve(G); ent_gene.reserve(G); ent_pham.reserve(G);
-    int maxlen = 0, minlen = G ? 0x7fffffff : 0;
-    for (int k = 0; k < G; ++k) {
-        const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
-        if (len < 0 || len > 65535) { pc_set_error("pc_upload: gene %d has length %lld (limit 65535)", k, (long long)len); return PC_ERR_LIMIT; }
-        gene_len[k] = (int32_t)len;
-        maxlen = std::max(maxlen, (int)len); minlen = std::min(minlen, (int)len);
+    std::vector<int> bad(N, 0);                          // per genome: 0 ok, else the error class found by the worker
+    {   // gene lengths
+        std::vector<int> over(1, -1);
+        parallel_chunks(G, [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; ++k) {
+                const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
+                if (len < 0 || len > 65535) { over[0] = (int)k; gene_len[k] = 0; } else gene_len[k] = (int32_t)len;   // (racy write of ONE reported index: any offender will do)
+            }
+        });
+        if (over[0] >= 0) {
+            const int k = over[0];
+            pc_set_error("pc_upload: gene %d has length %lld (limit 65535)", k, (long long)(g->seq_off[k + 1] - g->seq_off[k])); return PC_ERR_LIMIT;
+        }
     }
+    int maxlen = 0, minlen = G ? 0x7fffffff : 0;
+    for (int k = 0; k < G; ++k) { maxlen = std::max(maxlen, (int)gene_len[k]); minlen = std::min(minlen, (int)gene_len[k]); }
     for (int s = 0; s < N; ++s) {
         const int64_t k0 = g->gene_off[s], k1 = g->gene_off[s + 1];
         if (k1 < k0 || k1 > G) { pc_set_error("pc_upload: gene_off not monotone at genome %d", s); return PC_ERR_ARG; }
-        uint64_t* row = &bitmap[(size_t)s * Wstride];
-        memcpy(row, g->bitmap + (size_t)s * W, sizeof(uint64_t) * W);
-        const size_t ent0 = ent_cnt.size();
-        int64_t tl = 0;
-        for (int64_t k = k0; k < k1;) {
-            const int32_t p = g->gene_pham[k];
-            if (p < 0 || p >= P || !((row[p >> 6] >> (p & 63)) & 1ULL) || (k > k0 && g->gene_pham[k - 1] >= p && g->gene_pham[k - 1] != p)) {
-                pc_set_error("pc_upload: genome %d gene %lld: pham id %d out of order or not in bitmap", s, (long long)k, p); return PC_ERR_ARG;
+    }
+    // pass 1: entries (distinct phams) per genome = popcount of its bitmap row; the gene list is checked against it in pass 2
+    parallel_chunks(N, [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s) {
+            uint64_t* row = &bitmap[(size_t)s * Wstride];
+            memcpy(row, g->bitmap + (size_t)s * W, sizeof(uint64_t) * W);
+            size_t bits = 0;
+            for (int w = 0; w < W; ++w) bits += (size_t)__builtin_popcountll(row[w]);
+            ent_off[(size_t)s + 1] = (uint32_t)bits;
+        }
+    }, 64);
+    for (int s = 0; s < N; ++s) ent_off[(size_t)s + 1] += ent_off[s];
+    const size_t E = ent_off[N];
+    if (E > (size_t)G) { pc_set_error("pc_upload: the bitmap holds more phams than there are genes"); return PC_ERR_ARG; }
+    std::vector<int32_t> ent_cnt(E), ent_len(E), ent_gene(E), ent_pham(E);
+    // pass 2: a genome's entries, its rank table, and the consistency checks
+    parallel_chunks(N, [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t k0 = g->gene_off[s], k1 = g->gene_off[s + 1];
+            const uint64_t* row = &bitmap[(size_t)s * Wstride];
+            const size_t ent0 = ent_off[s], cap = ent_off[(size_t)s + 1] - ent0;
+            size_t ne = 0; int64_t tl = 0; int err = 0;
+            for (int64_t k = k0; k < k1 && !err;) {
+                const int32_t p = g->gene_pham[k];
+                if (p < 0 || p >= P || !((row[p >> 6] >> (p & 63)) & 1ULL) || (k > k0 && g->gene_pham[k - 1] >= p && g->gene_pham[k - 1] != p)) { err = 1; break; }
+                int64_t k2 = k; int64_t ln = 0;
+                while (k2 < k1 && g->gene_pham[k2] == p) { ln += gene_len[k2]; ++k2; }
+                if (ne >= cap) { err = 2; break; }
+                ent_cnt[ent0 + ne] = (int32_t)(k2 - k); ent_len[ent0 + ne] = (int32_t)ln; ent_gene[ent0 + ne] = (int32_t)k; ent_pham[ent0 + ne] = p;
+                ++ne; tl += ln; k = k2;
             }
-            int64_t k2 = k; int64_t ln = 0;
-            while (k2 < k1 && g->gene_pham[k2] == p) { ln += gene_len[k2]; ++k2; }
-            ent_cnt.push_back((int32_t)(k2 - k)); ent_len.push_back((int32_t)ln); ent_gene.push_back((int32_t)k); ent_pham.push_back(p);
-            tl += ln; k = k2;
+            size_t bits = 0;
+            for (int w = 0; w < W; ++w) { rankpre[(size_t)s * W + w] = (uint32_t)(ent0 + bits); bits += (size_t)__builtin_popcountll(row[w]); }
+            if (!err && (ne != cap || (int)ne != g->nph[s] || (int)(k1 - k0) != g->ngen[s] || tl != g->tlen[s])) err = 2;
+            bad[s] = err;
         }
-        ent_off[(size_t)s + 1] = (uint32_t)ent_cnt.size();
-        const size_t nent = ent_cnt.size() - ent0;
-        size_t bits = 0;
-        for (int w = 0; w < W; ++w) { rankpre[(size_t)s * W + w] = (uint32_t)(ent0 + bits); bits += (size_t)__builtin_popcountll(row[w]); }
-        if (bits != nent || (int)nent != g->nph[s] || (int)(k1 - k0) != g->ngen[s] || tl != g->tlen[s]) {
-            pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG;
-        }
+    }, 64);
+    for (int s = 0; s < N; ++s) {
+        if (bad[s] == 1) { pc_set_error("pc_upload: genome %d: a gene's pham id is out of order or not in the bitmap", s); return PC_ERR_ARG; }
+        if (bad[s] == 2) { pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG; }
     }
     lap("entries, rank table");
     std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
@@ -442,38 +469,43 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     std::vector<int64_t> gene_off(G);
     int64_t code_bytes = 0;
     for (int k = 0; k < G; ++k) { gene_off[k] = code_bytes; code_bytes += ((int64_t)gene_len[k] + 15) & ~15LL; }
-    // encoded residues (16-byte padded per gene) and a 64-bit hash of each gene's codes, on several host threads
-    // (not a std::vector: value-initialising ~10^8 bytes on one thread cost as much as encoding them on sixteen; the worker
-    // threads below are the first to touch their part)
-    const size_t codes_size = (size_t)std::max<int64_t>(code_bytes, 16);
-    std::unique_ptr<uint8_t[]> codes(new (std::nothrow) uint8_t[codes_size]);
-    if (!codes) { pc_set_error("pc_upload: out of host memory (%zu bytes of residue codes)", codes_size); return PC_ERR_LIMIT; }
-    if (code_bytes < 16) memset(codes.get(), PC_PADCODE, 16);
+    // The residues go to the device RAW and are encoded there (k_encode: code LUT, 16-byte padding per gene): the host only
+    // hashes them -- 8 raw bytes per multiply -- and notes which genes hold a byte outside the alphabet.  (r02 encoded on the
+    // host: a 10^8-byte buffer to fault in, fill through the LUT byte by byte, copy and unmap per upload.)  Hashing the raw
+    // bytes means two translations that differ only in letter case count as two sequences: they are aligned twice, nothing else.
     std::vector<uint64_t> ghash(std::max(G, 1));
     std::vector<uint8_t> godd(std::max(G, 1), 0);      // gene holds a byte outside the 24-letter alphabet (code >= 24)
     uint8_t lut[256]; build_code_lut(lut);
+    uint8_t is_odd[256];
+    for (int v = 0; v < 256; ++v) is_odd[v] = (uint8_t)(lut[v] >= 24);
+    const uint8_t* raw = g->residues;
     parallel_chunks(G, [&](int64_t k0, int64_t k1) {
         for (int64_t k = k0; k < k1; ++k) {
-            const uint8_t* src = g->residues + g->seq_off[k]; uint8_t* dst = &codes[(size_t)gene_off[k]];
-            const int len = gene_len[k], padded = (len + 15) & ~15;
-            uint8_t top = 0;
-            for (int i = 0; i < len; ++i) { dst[i] = lut[src[i]]; top |= (uint8_t)(dst[i] >= 24); }
-            godd[k] = top;
-            for (int i = len; i < padded; ++i) dst[i] = (uint8_t)PC_PADCODE;
-            // hash of the padded codes, 8 bytes per multiply (a byte-wise multiply chain cost as much as the encoding itself);
-            // equal hash and length are confirmed by comparing the codes, so only its spread matters
+            const uint8_t* src = raw + g->seq_off[k];
+            const int len = gene_len[k];
             uint64_t h = 0x9e3779b97f4a7c15ULL ^ (uint64_t)len;
-            for (int i = 0; i < padded; i += 8) { uint64_t w; memcpy(&w, dst + i, 8); h = (h ^ w) * 0x9fb21c651e98df25ULL; h ^= h >> 32; }
+            uint8_t odd = 0;
+            int i = 0;
+            for (; i + 8 <= len; i += 8) {
+                uint64_t w; memcpy(&w, src + i, 8);
+                h = (h ^ w) * 0x9fb21c651e98df25ULL; h ^= h >> 32;
+                odd |= (uint8_t)(is_odd[src[i]] | is_odd[src[i + 1]] | is_odd[src[i + 2]] | is_odd[src[i + 3]] | is_odd[src[i + 4]] | is_odd[src[i + 5]] |
+                                 is_odd[src[i + 6]] | is_odd[src[i + 7]]);
+            }
+            uint64_t w = 0;
+            for (int j = 0; i + j < len; ++j) { w |= (uint64_t)src[i + j] << (8 * j); odd |= is_odd[src[i + j]]; }
+            h = (h ^ w) * 0x9fb21c651e98df25ULL; h ^= h >> 32;
             ghash[k] = h ^ (h >> 29);
+            godd[k] = odd;
         }
     });
-    lap("residue codes");
-    // distinct sequences (by encoded residues: what the kernels compare).  Alignments are planned per distinct
+    lap("residue hashes");
+    // distinct sequences (by raw residues).  Alignments are planned per distinct
     // (row sequence, column sequence) pair, so every sequence gets a rank q; ranks follow launch-class order: column
     // sequences grouped by the kernel variant that aligns against them and by lanes-per-segment bucket (the
     // profile's LDS footprint scales with it, and LDS sets occupancy)
     std::vector<int32_t> uid(G), u_gene;
-    {   // open-addressing table over the precomputed hashes; equal hash and length are confirmed by comparing the codes
+    {   // open-addressing table over the precomputed hashes; equal hash and length are confirmed by comparing the residues
         size_t cap = 16;
         while (cap < (size_t)G * 2) cap <<= 1;
         std::vector<int32_t> slot(cap, -1);
@@ -484,7 +516,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
                 if (u < 0) { slot[pos] = (int32_t)u_gene.size(); uid[k] = (int32_t)u_gene.size(); u_gene.push_back(k); break; }
                 const int r = u_gene[u];
                 if (ghash[r] == ghash[k] && gene_len[r] == gene_len[k] &&
-                    !memcmp(&codes[(size_t)gene_off[r]], &codes[(size_t)gene_off[k]], (size_t)gene_len[k])) { uid[k] = u; break; }
+                    !memcmp(raw + g->seq_off[r], raw + g->seq_off[k], (size_t)gene_len[k])) { uid[k] = u; break; }
             }
         }
     }
@@ -544,34 +576,65 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
         for (int len = 0; len <= maxlen; ++len) at[len + 1] += at[len];
         for (int u = 0; u < U; ++u) u_order[at[gene_len[u_gene[u]]]++] = u;
     }
-    for (int u : u_order) {
-        const int q = (int)cls_pos[u_cls[u]]++;
-        const int len = gene_len[u_gene[u]];
-        q_of_u[u] = (uint32_t)q; q_gene[q] = u_gene[u];
-        q_class[q] = (uint8_t)u_cls[u];
-        if (u_cls[u] == ncls_all - 1) { task_rows[q] = pc_nw_task_rows(len, -1, 0); q_nseg[q] = 1; }   // general kernel (rem_class stays 255: no remainder move)
-        else if (!godd[u_gene[u]] || u_cls[u] == len_cls[len]) { task_rows[q] = len_rows[len]; q_nseg[q] = len_nseg[len]; memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16); }
-        else {                                                   // "any byte" class: its own task size, remainders to the "any byte" class of their variant
-            task_rows[q] = pc_nw_task_rows(len, len_var[len], 1); q_nseg[q] = len_nseg[len];
+    for (int u : u_order) q_of_u[u] = (uint32_t)cls_pos[u_cls[u]]++;        // (serial: a rank is its predecessors' count)
+    {   // "any byte" classes a remainder may be sent to: their longest column gene (serial, rare)
+        for (int u = 0; u < U; ++u) {
+            const int len = gene_len[u_gene[u]];
+            if (!godd[u_gene[u]] || u_cls[u] == len_cls[len] || u_cls[u] == ncls_all - 1) continue;
             for (int r = 1; r < 16; ++r) {
                 const uint8_t cr = len_rem[(size_t)len * 16 + r];
                 if (cr == 255) continue;
                 const int ca = pc_class_of(len, pc_class_variant(cr), true);
-                rem_class[(size_t)q * 16 + r] = (uint8_t)ca;
                 c->cls_max_lb[ca] = std::max(c->cls_max_lb[ca], len);
             }
         }
     }
-    for (int k = 0; k < G; ++k) gene_q[k] = q_of_u[uid[k]];
+    parallel_chunks(U, [&](int64_t u0, int64_t u1) {
+        for (int64_t u = u0; u < u1; ++u) {
+            const int q = (int)q_of_u[u];
+            const int len = gene_len[u_gene[u]];
+            q_gene[q] = u_gene[u];
+            q_class[q] = (uint8_t)u_cls[u];
+            if (u_cls[u] == ncls_all - 1) { task_rows[q] = pc_nw_task_rows(len, -1, 0); q_nseg[q] = 1; }   // general kernel (rem_class stays 255: no remainder move)
+            else if (!godd[u_gene[u]] || u_cls[u] == len_cls[len]) { task_rows[q] = len_rows[len]; q_nseg[q] = len_nseg[len]; memcpy(&rem_class[(size_t)q * 16], &len_rem[(size_t)len * 16], 16); }
+            else {                                                   // "any byte" class: its own task size, remainders to the "any byte" class of their variant
+                task_rows[q] = pc_nw_task_rows(len, len_var[len], 1); q_nseg[q] = len_nseg[len];
+                for (int r = 1; r < 16; ++r) {
+                    const uint8_t cr = len_rem[(size_t)len * 16 + r];
+                    if (cr == 255) continue;
+                    rem_class[(size_t)q * 16 + r] = (uint8_t)pc_class_of(len, pc_class_variant(cr), true);
+                }
+            }
+        }
+    });
+    parallel_chunks(G, [&](int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; ++k) gene_q[k] = q_of_u[uid[k]]; });
     int ubits = 1;
     while ((1LL << ubits) < U) ++ubits;
 
     lap("launch classes");
     // ---- device copies ---------------------------------------------------------------
-    if ((rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_raw(c->b_codes, codes.get(), codes_size)) ||
+    const size_t codes_size = (size_t)std::max<int64_t>(code_bytes, 16);
+    const int64_t raw_bytes = g->seq_off[G] - g->seq_off[0];
+    {   // raw residues + their offsets -> device, encoded there, the two staging buffers freed again
+        DevBuf d_raw, d_seq_off;
+        std::vector<int64_t> rel(g->seq_off, g->seq_off + G + 1);
+        for (auto& x : rel) x -= g->seq_off[0];
+        PcLut lut_arg;
+        memcpy(lut_arg.v, lut, 256);
+        if ((rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_raw(d_raw, raw + g->seq_off[0], (size_t)raw_bytes)) || (rc = upload_vec(d_seq_off, rel)) ||
+            (rc = abi_rc(c->b_codes.ensure(codes_size)))) { d_raw.release(); d_seq_off.release(); return rc; }
+        if (code_bytes < 16) PC_HIP(hipMemsetAsync(c->b_codes.p, PC_PADCODE, 16, c->stream));
+        rc = pc_launch_encode(d_raw.as<uint8_t>(), d_seq_off.as<int64_t>(), c->b_gene_off.as<int64_t>(), c->b_gene_len.as<int32_t>(), lut_arg,
+                              c->b_codes.as<uint8_t>(), G, c->stream);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        d_raw.release(); d_seq_off.release();
+        if (rc != PC_OK) return rc;
+        if (e != hipSuccess) { pc_set_error("pc_upload: residue encoding: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    }
+    if (
         (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
         (rc = upload_vec(c->b_q_class, q_class)) || (rc = upload_vec(c->b_q_nseg, q_nseg)) || (rc = upload_vec(c->b_rem_class, rem_class)) ||
-        (rc = c->b_cls_begin.ensure((ncls_all + 1) * 4)))
+        (rc = abi_rc(c->b_cls_begin.ensure((ncls_all + 1) * 4))))
         return rc;
     c->task_plan.task_rows = c->b_task_rows.as<int32_t>(); c->task_plan.q_class = c->b_q_class.as<uint8_t>();
     c->task_plan.q_nseg = c->b_q_nseg.as<uint8_t>(); c->task_plan.rem_class = c->b_rem_class.as<uint8_t>();

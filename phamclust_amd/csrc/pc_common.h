@@ -93,6 +93,11 @@ int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs
 int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st);   // pocp / af
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
+// residue bytes -> codes on the device (pc_plan.hip): gene k's raw bytes [seq_off[k], seq_off[k+1]) go through the LUT to
+// codes + gene_off[k], padded with PC_PADCODE to a multiple of 16
+struct PcLut { uint8_t v[256]; };
+int pc_launch_encode(const uint8_t* raw, const int64_t* seq_off, const int64_t* gene_off, const int32_t* gene_len, const PcLut& lut,
+                     uint8_t* codes, int G, hipStream_t st);
 // planning of the alignment batch (pc_plan.hip)
 int pc_launch_task_keys(const PcDev& d, const PcTask* tasks, unsigned long long* key, uint32_t* val, int ntasks, hipStream_t st);
 int pc_launch_task_gather(const PcTask* in, const uint32_t* idx, PcTask* out, int ntasks, hipStream_t st);

@@ -196,3 +196,31 @@ int pc_launch_class_bounds(const unsigned long long* sorted_key, int ntasks, int
     hipLaunchKernelGGL(k_class_bounds, dim3((ncls + 1 + 63) / 64), dim3(64), 0, st, sorted_key, ntasks, ncls, cls_begin);
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
+
+
+// ---------------------------------------------------------------------------------
+// Residue bytes -> codes (pc_upload_residues): one wave per gene, 64 bytes per step; the LUT rides in the kernel arguments.
+// Alphabet letters (either case) -> 0..23 in BLOSUM62 order, every other byte value its own code, padding PC_PADCODE.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ raw, const int64_t* __restrict__ seq_off,
+                                                 const int64_t* __restrict__ gene_off, const int32_t* __restrict__ gene_len, PcLut lut,
+                                                 uint8_t* __restrict__ codes, int G) {
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= G) return;
+    const uint8_t* src = raw + seq_off[k];
+    uint8_t* dst = codes + gene_off[k];
+    const int len = gene_len[k], padded = (len + 15) & ~15;
+    for (int i = lane; i < padded; i += 64) dst[i] = i < len ? s_lut[src[i]] : (uint8_t)PC_PADCODE;
+}
+
+int pc_launch_encode(const uint8_t* raw, const int64_t* seq_off, const int64_t* gene_off, const int32_t* gene_len, const PcLut& lut,
+                     uint8_t* codes, int G, hipStream_t st) {
+    if (G <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, st, raw, seq_off, gene_off, gene_len, lut, codes, G);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_encode launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
