@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
 // the three (51 us against a 16 us popcount floor; counting alone 32 us, `tools/popc_experiment.sh`).  Here a wave carries
 // a quarter of that, so 8,064 of them deal out evenly, and the ~8 waves per SIMD hide each other's LDS and staging waits.
 // The staging buffers double as the partial-sum array once the last chunk has been counted.
+// (Tried on top: wave-PRIVATE staging -- each wave loads the 20 words it will count for all 64 rows in one burst, no workgroup
+// barrier before the final reduction -- 43 KB of LDS instead of 17: N = 2,000 36 -> 43 us, N = 5,000 166 -> 210: the nine
+// resident workgroups per CU hide more than the barriers cost.)
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
                                                           const double* __restrict__ lut, int sh_dim) {
