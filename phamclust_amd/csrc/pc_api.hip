@@ -142,7 +142,10 @@ struct pc_ctx {
     std::vector<int32_t> h_owned;           // this rank's targets, ascending, and
     std::vector<int64_t> h_lbase;           // [nown+1] the shard-local index of pair (0, owned[k]) (host copies of shard.owned / lbase)
     // persistent device arrays
-    DevBuf b_ent_pham, b_ent_off;
+    DevBuf b_raw, b_seq_tmp;                // part 2's staging: the raw residue bytes and their offsets, as uploaded (encoded into b_codes on the device)
+    DevBuf b_sets;                          // part 1 of the upload, one allocation: bitmap | rank table | gene lengths | entry offsets | nph | ngen | tlen | 4 entry arrays
+    uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;   // its page-locked host image (grow-only)
+    uint8_t* h_raw = nullptr; size_t h_raw_cap = 0;       // page-locked staging of the raw residues (part 2; grow-only, <= 512 MB)
     DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
     DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
@@ -241,7 +244,9 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     PcDeviceGuard guard(c->device);
     if (c->busy && c->ev_last) (void)hipEventSynchronize(c->ev_last);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->b_ent_pham, &c->b_ent_off, &c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_raw) (void)hipHostFree(c->h_raw);
+    DevBuf* bufs[] = {&c->b_raw, &c->b_seq_tmp, &c->b_sets, &c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
                       &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
@@ -348,12 +353,29 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     c->uploaded = false; c->residues_ready = false; c->target_cost.clear(); c->plan.valid = false;
     PC_HIP(hipStreamSynchronize(c->stream));
 
-    // ---- host-side indices (on several threads: genomes are independent once every genome knows where its entries start)
+    // ---- host-side indices, written straight into ONE page-locked staging buffer the context keeps (grow-only) and sent with
+    // ONE copy (eleven pageable copies were 1.2 of the 1.9 ms of this stage at N = 2,000).  Several threads: genomes are
+    // independent once every genome knows where its entries start.
     const int Wstride = W | 1;
-    std::vector<uint64_t> bitmap((size_t)N * Wstride, 0);
-    std::vector<uint32_t> rankpre((size_t)N * W);
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_bitmap = place((size_t)N * Wstride * 8), o_rankpre = place((size_t)N * W * 4), o_gene_len = place((size_t)std::max(G, 1) * 4),
+                 o_ent_off = place(((size_t)N + 1) * 4), o_nph = place((size_t)N * 4), o_ngen = place((size_t)N * 4), o_tlen = place((size_t)N * 8);
+    const size_t o_ent = off;                                           // four entry arrays of E <= G elements follow
+    const size_t cap_bytes = o_ent + 4 * (((size_t)std::max(G, 1) * 4 + 255) & ~(size_t)255);
+    if (cap_bytes > c->h_stage_cap) {
+        if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+        const size_t want = cap_bytes + cap_bytes / 8;
+        hipError_t e = hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault);
+        if (e != hipSuccess) { pc_set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); c->h_stage = nullptr; return PC_ERR_HIP; }
+        c->h_stage_cap = want;
+    }
+    uint8_t* hs = c->h_stage;
+    uint64_t* bitmap = (uint64_t*)(hs + o_bitmap); uint32_t* rankpre = (uint32_t*)(hs + o_rankpre); int32_t* gene_len_h = (int32_t*)(hs + o_gene_len);
+    uint32_t* ent_off = (uint32_t*)(hs + o_ent_off); int32_t* nph_h = (int32_t*)(hs + o_nph); int32_t* ngen_h = (int32_t*)(hs + o_ngen);
+    int64_t* tlen_h = (int64_t*)(hs + o_tlen);
+    memcpy(nph_h, g->nph, (size_t)N * 4); memcpy(ngen_h, g->ngen, (size_t)N * 4); memcpy(tlen_h, g->tlen, (size_t)N * 8);
     std::vector<int32_t> gene_len(G);
-    std::vector<uint32_t> ent_off((size_t)N + 1, 0);
     std::vector<int> bad(N, 0);                          // per genome: 0 ok, else the error class found by the worker
     {   // gene lengths
         std::vector<int> over(1, -1);
@@ -361,6 +383,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
             for (int64_t k = k0; k < k1; ++k) {
                 const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
                 if (len < 0 || len > 65535) { over[0] = (int)k; gene_len[k] = 0; } else gene_len[k] = (int32_t)len;   // (racy write of ONE reported index: any offender will do)
+                gene_len_h[k] = gene_len[k];
             }
         });
         if (over[0] >= 0) {
@@ -375,10 +398,12 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         if (k1 < k0 || k1 > G) { pc_set_error("pc_upload: gene_off not monotone at genome %d", s); return PC_ERR_ARG; }
     }
     // pass 1: entries (distinct phams) per genome = popcount of its bitmap row; the gene list is checked against it in pass 2
+    ent_off[0] = 0;
     parallel_chunks(N, [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s) {
-            uint64_t* row = &bitmap[(size_t)s * Wstride];
+            uint64_t* row = bitmap + (size_t)s * Wstride;
             memcpy(row, g->bitmap + (size_t)s * W, sizeof(uint64_t) * W);
+            for (int w = W; w < Wstride; ++w) row[w] = 0;
             size_t bits = 0;
             for (int w = 0; w < W; ++w) bits += (size_t)__builtin_popcountll(row[w]);
             ent_off[(size_t)s + 1] = (uint32_t)bits;
@@ -387,12 +412,15 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     for (int s = 0; s < N; ++s) ent_off[(size_t)s + 1] += ent_off[s];
     const size_t E = ent_off[N];
     if (E > (size_t)G) { pc_set_error("pc_upload: the bitmap holds more phams than there are genes"); return PC_ERR_ARG; }
-    std::vector<int32_t> ent_cnt(E), ent_len(E), ent_gene(E), ent_pham(E);
+    const size_t ent_stride = ((size_t)std::max<size_t>(E, 1) * 4 + 255) & ~(size_t)255;
+    int32_t* ent_cnt = (int32_t*)(hs + o_ent); int32_t* ent_len = (int32_t*)(hs + o_ent + ent_stride);
+    int32_t* ent_gene = (int32_t*)(hs + o_ent + 2 * ent_stride); int32_t* ent_pham = (int32_t*)(hs + o_ent + 3 * ent_stride);
+    const size_t total_bytes = o_ent + 4 * ent_stride;
     // pass 2: a genome's entries, its rank table, and the consistency checks
     parallel_chunks(N, [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s) {
             const int64_t k0 = g->gene_off[s], k1 = g->gene_off[s + 1];
-            const uint64_t* row = &bitmap[(size_t)s * Wstride];
+            const uint64_t* row = bitmap + (size_t)s * Wstride;
             const size_t ent0 = ent_off[s], cap = ent_off[(size_t)s + 1] - ent0;
             size_t ne = 0; int64_t tl = 0; int err = 0;
             for (int64_t k = k0; k < k1 && !err;) {
@@ -415,21 +443,22 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         if (bad[s] == 2) { pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG; }
     }
     lap("entries, rank table");
-    std::vector<int32_t> nph(g->nph, g->nph + N), ngen(g->ngen, g->ngen + N);
-    std::vector<int64_t> tlen(g->tlen, g->tlen + N);
-    if ((rc = upload_vec(c->b_bitmap, bitmap)) || (rc = upload_vec(c->b_rankpre, rankpre)) || (rc = upload_vec(c->b_ent_cnt, ent_cnt)) ||
-        (rc = upload_vec(c->b_ent_len, ent_len)) || (rc = upload_vec(c->b_ent_gene, ent_gene)) || (rc = upload_vec(c->b_gene_len, gene_len)) ||
-        (rc = upload_vec(c->b_ent_pham, ent_pham)) || (rc = upload_vec(c->b_ent_off, ent_off)) ||
-        (rc = upload_vec(c->b_nph, nph)) || (rc = upload_vec(c->b_ngen, ngen)) || (rc = upload_vec(c->b_tlen, tlen)))
-        return rc;
+    if ((rc = abi_rc(c->b_sets.ensure(total_bytes)))) return rc;
+    // (an idle GPU answers its first command after 10-25 ms, whatever the command -- DMA copy, blocking copy or a copy
+    // kernel all showed it when uploads followed each other with nothing in between, `tools/upload_timing.py`; that is the
+    // device waking up, not this copy: behind a fill the same copy takes 0.3 ms)
+    PC_HIP(hipMemcpyAsync(c->b_sets.p, hs, total_bytes, hipMemcpyHostToDevice, c->stream));
+    PC_HIP(hipStreamSynchronize(c->stream));
+    lap("h2d sets");
+    uint8_t* ds = (uint8_t*)c->b_sets.p;
     PcDev& d = c->dev;
     memset(&d, 0, sizeof(d));
-    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)ent_cnt.size();
-    d.bitmap = c->b_bitmap.as<uint64_t>(); d.rankpre = c->b_rankpre.as<uint32_t>();
-    d.ent_cnt = c->b_ent_cnt.as<int32_t>(); d.ent_len = c->b_ent_len.as<int32_t>(); d.ent_gene = c->b_ent_gene.as<int32_t>();
-    d.gene_len = c->b_gene_len.as<int32_t>();
-    d.ent_pham = c->b_ent_pham.as<int32_t>(); d.ent_off = c->b_ent_off.as<uint32_t>();
-    d.nph = c->b_nph.as<int32_t>(); d.ngen = c->b_ngen.as<int32_t>(); d.tlen = c->b_tlen.as<int64_t>();
+    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)E;
+    d.bitmap = (const uint64_t*)(ds + o_bitmap); d.rankpre = (const uint32_t*)(ds + o_rankpre);
+    d.ent_cnt = (const int32_t*)(ds + o_ent); d.ent_len = (const int32_t*)(ds + o_ent + ent_stride);
+    d.ent_gene = (const int32_t*)(ds + o_ent + 2 * ent_stride); d.ent_pham = (const int32_t*)(ds + o_ent + 3 * ent_stride);
+    d.gene_len = (const int32_t*)(ds + o_gene_len); d.ent_off = (const uint32_t*)(ds + o_ent_off);
+    d.nph = (const int32_t*)(ds + o_nph); d.ngen = (const int32_t*)(ds + o_ngen); d.tlen = (const int64_t*)(ds + o_tlen);
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
     c->max_nph = 0;
@@ -479,7 +508,23 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     uint8_t is_odd[256];
     for (int v = 0; v < 256; ++v) is_odd[v] = (uint8_t)(lut[v] >= 24);
     const uint8_t* raw = g->residues;
+    // The hashing threads also copy their genes' bytes into a page-locked staging buffer the context keeps (up to 512 MB;
+    // beyond that the residues go over from the caller's pageable memory at the end), and the DMA to HBM is started as soon as
+    // they are done: it runs behind the de-duplication and the launch-class tables below.
+    const int64_t raw_bytes = g->seq_off[G] - g->seq_off[0];
+    const bool staged = raw_bytes > 0 && raw_bytes <= ((int64_t)512 << 20);
+    if (staged && (size_t)raw_bytes > c->h_raw_cap) {
+        if (c->h_raw) { (void)hipHostFree(c->h_raw); c->h_raw = nullptr; c->h_raw_cap = 0; }
+        const size_t want = (size_t)raw_bytes + (size_t)raw_bytes / 8;
+        hipError_t e = hipHostMalloc((void**)&c->h_raw, want, hipHostMallocDefault);
+        if (e != hipSuccess) { pc_set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); c->h_raw = nullptr; return PC_ERR_HIP; }
+        c->h_raw_cap = want;
+    }
+    if ((rc = abi_rc(c->b_raw.ensure((size_t)std::max<int64_t>(raw_bytes, 16))))) return rc;
+    uint8_t* const stage = staged ? c->h_raw : nullptr;
+    const int64_t raw0 = g->seq_off[0];
     parallel_chunks(G, [&](int64_t k0, int64_t k1) {
+        if (stage) memcpy(stage + (g->seq_off[k0] - raw0), raw + g->seq_off[k0], (size_t)(g->seq_off[k1] - g->seq_off[k0]));
         for (int64_t k = k0; k < k1; ++k) {
             const uint8_t* src = raw + g->seq_off[k];
             const int len = gene_len[k];
@@ -499,6 +544,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
             godd[k] = odd;
         }
     });
+    if (staged) PC_HIP(hipMemcpyAsync(c->b_raw.p, stage, (size_t)raw_bytes, hipMemcpyHostToDevice, c->stream));
     lap("residue hashes");
     // distinct sequences (by raw residues).  Alignments are planned per distinct
     // (row sequence, column sequence) pair, so every sequence gets a rank q; ranks follow launch-class order: column
@@ -614,20 +660,19 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     lap("launch classes");
     // ---- device copies ---------------------------------------------------------------
     const size_t codes_size = (size_t)std::max<int64_t>(code_bytes, 16);
-    const int64_t raw_bytes = g->seq_off[G] - g->seq_off[0];
-    {   // raw residues + their offsets -> device, encoded there, the two staging buffers freed again
-        DevBuf d_raw, d_seq_off;
+    {   // raw residues + their offsets -> device, encoded there.  The two staging buffers stay with the context (grow-only):
+        // a hipFree of ~10^8 bytes per upload made the NEXT copy on the context wait 8-25 ms
+        DevBuf& d_raw = c->b_raw; DevBuf& d_seq_off = c->b_seq_tmp;
         std::vector<int64_t> rel(g->seq_off, g->seq_off + G + 1);
         for (auto& x : rel) x -= g->seq_off[0];
         PcLut lut_arg;
         memcpy(lut_arg.v, lut, 256);
-        if ((rc = upload_vec(c->b_gene_off, gene_off)) || (rc = upload_raw(d_raw, raw + g->seq_off[0], (size_t)raw_bytes)) || (rc = upload_vec(d_seq_off, rel)) ||
-            (rc = abi_rc(c->b_codes.ensure(codes_size)))) { d_raw.release(); d_seq_off.release(); return rc; }
+        if ((rc = upload_vec(c->b_gene_off, gene_off)) || (!staged && (rc = upload_raw(d_raw, raw + g->seq_off[0], (size_t)raw_bytes))) || (rc = upload_vec(d_seq_off, rel)) ||
+            (rc = abi_rc(c->b_codes.ensure(codes_size)))) return rc;
         if (code_bytes < 16) PC_HIP(hipMemsetAsync(c->b_codes.p, PC_PADCODE, 16, c->stream));
-        rc = pc_launch_encode(d_raw.as<uint8_t>(), d_seq_off.as<int64_t>(), c->b_gene_off.as<int64_t>(), c->b_gene_len.as<int32_t>(), lut_arg,
+        rc = pc_launch_encode(d_raw.as<uint8_t>(), d_seq_off.as<int64_t>(), c->b_gene_off.as<int64_t>(), c->dev.gene_len, lut_arg,
                               c->b_codes.as<uint8_t>(), G, c->stream);
         hipError_t e = hipStreamSynchronize(c->stream);
-        d_raw.release(); d_seq_off.release();
         if (rc != PC_OK) return rc;
         if (e != hipSuccess) { pc_set_error("pc_upload: residue encoding: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     }

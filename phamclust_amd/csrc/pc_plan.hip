@@ -224,3 +224,4 @@ int pc_launch_encode(const uint8_t* raw, const int64_t* seq_off, const int64_t* 
     if (e != hipSuccess) { pc_set_error("k_encode launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
 }
+
