@@ -126,7 +126,7 @@ struct pc_ctx {
     PcDev dev{};
     std::vector<int32_t> h_gene_len;
     std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
-    int max_gene_len = 0, min_gene_len = 0, max_nph = 0;
+    int max_gene_len = 0, min_gene_len = 0, max_nph = 0, max_ngen = 0;
     // kernel-variant classes over column genes
     int ncls_all = 0;                       // launch classes: variant * 4 + lanes-per-segment bucket, last = general kernel
     std::vector<int32_t> cls_max_lb;        // [ncls_all] longest column sequence that can land in the class (LDS size of its launch)
@@ -362,7 +362,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     const size_t o_bitmap = place((size_t)N * Wstride * 8), o_rankpre = place((size_t)N * W * 4), o_gene_len = place((size_t)std::max(G, 1) * 4),
                  o_ent_off = place(((size_t)N + 1) * 4), o_nph = place((size_t)N * 4), o_ngen = place((size_t)N * 4), o_tlen = place((size_t)N * 8);
     const size_t o_ent = off;                                           // four entry arrays of E <= G elements follow
-    const size_t cap_bytes = o_ent + 4 * (((size_t)std::max(G, 1) * 4 + 255) & ~(size_t)255);
+    const size_t cap_bytes = o_ent + 6 * (((size_t)std::max(G, 1) * 4 + 255) & ~(size_t)255) + (((size_t)N + 1) * 4 + 255);   // + the paralog lists
     if (cap_bytes > c->h_stage_cap) {
         if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
         const size_t want = cap_bytes + cap_bytes / 8;
@@ -442,12 +442,33 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         if (bad[s] == 1) { pc_set_error("pc_upload: genome %d: a gene's pham id is out of order or not in the bitmap", s); return PC_ERR_ARG; }
         if (bad[s] == 2) { pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG; }
     }
+    // paralog lists (pocp): a genome's entries with more than one gene, as (pham, count - 1).  conserved proteins of a pair =
+    // 2 x shared phams + the excess counts of the shared paralog phams, and only ~6 % of the entries are paralogs
+    const size_t o_para_off = (o_ent + 4 * ent_stride + 255) & ~(size_t)255;
+    uint32_t* para_off = (uint32_t*)(hs + o_para_off);
+    const size_t o_para = (o_para_off + ((size_t)N + 1) * 4 + 255) & ~(size_t)255;
+    size_t n_para = 0;
+    for (size_t e = 0; e < E; ++e) n_para += ent_cnt[e] > 1;
+    const size_t para_stride = ((size_t)std::max<size_t>(n_para, 1) * 4 + 255) & ~(size_t)255;
+    int32_t* para_pham = (int32_t*)(hs + o_para); int32_t* para_ex = (int32_t*)(hs + o_para + para_stride);
+    {
+        size_t at = 0; int max_ngen = 0;
+        for (int s2 = 0; s2 < N; ++s2) {
+            para_off[s2] = (uint32_t)at;
+            for (size_t e = ent_off[s2]; e < ent_off[(size_t)s2 + 1]; ++e)
+                if (ent_cnt[e] > 1) { para_pham[at] = ent_pham[e]; para_ex[at] = ent_cnt[e] - 1; ++at; }
+            max_ngen = std::max(max_ngen, (int)g->ngen[s2]);
+        }
+        para_off[N] = (uint32_t)at;
+        c->max_ngen = max_ngen;
+    }
+    const size_t total_bytes2 = o_para + 2 * para_stride;
     lap("entries, rank table");
-    if ((rc = abi_rc(c->b_sets.ensure(total_bytes)))) return rc;
+    if ((rc = abi_rc(c->b_sets.ensure(total_bytes2)))) return rc;
     // (an idle GPU answers its first command after 10-25 ms, whatever the command -- DMA copy, blocking copy or a copy
     // kernel all showed it when uploads followed each other with nothing in between, `tools/upload_timing.py`; that is the
     // device waking up, not this copy: behind a fill the same copy takes 0.3 ms)
-    PC_HIP(hipMemcpyAsync(c->b_sets.p, hs, total_bytes, hipMemcpyHostToDevice, c->stream));
+    PC_HIP(hipMemcpyAsync(c->b_sets.p, hs, total_bytes2, hipMemcpyHostToDevice, c->stream));
     PC_HIP(hipStreamSynchronize(c->stream));
     lap("h2d sets");
     uint8_t* ds = (uint8_t*)c->b_sets.p;
@@ -459,6 +480,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     d.ent_gene = (const int32_t*)(ds + o_ent + 2 * ent_stride); d.ent_pham = (const int32_t*)(ds + o_ent + 3 * ent_stride);
     d.gene_len = (const int32_t*)(ds + o_gene_len); d.ent_off = (const uint32_t*)(ds + o_ent_off);
     d.nph = (const int32_t*)(ds + o_nph); d.ngen = (const int32_t*)(ds + o_ngen); d.tlen = (const int64_t*)(ds + o_tlen);
+    d.para_off = (const uint32_t*)(ds + o_para_off); d.para_pham = (const int32_t*)(ds + o_para); d.para_ex = (const int32_t*)(ds + o_para + para_stride);
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
     c->max_nph = 0;
@@ -1166,15 +1188,18 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     as_distance = as_distance ? 1 : 0;
     PC_HIP(hipEventRecord(c->ev[0], st));
 
-    if (metric == PC_GCS || metric == PC_JC) {
-        // epilogue table over (shared, nph_s + nph_t): at most (max_nph+1) x (2 max_nph+1) doubles; skipped when huge.
-        // It depends on (metric, as_distance, max_nph) only, so it is rebuilt only when one of them changes.
-        const int sh_dim = c->max_nph + 1, tot_dim = 2 * c->max_nph + 1;
+    static const char* set_force = getenv("PC_SET_KERNEL");          // A/B knob: walker | sparse force the older pocp / af kernels
+    if (metric == PC_GCS || metric == PC_JC || (metric == PC_POCP && !set_force)) {
+        // epilogue table: gcs / jc over (shared, nph_s + nph_t), at most (max_nph+1) x (2 max_nph+1) doubles; pocp over
+        // (conserved, ngen_s + ngen_t), (2 max_ngen+1)^2; skipped when huge.  It depends on (metric, as_distance, that maximum)
+        // only, so it is rebuilt only when one of them changes.
+        const int top = metric == PC_POCP ? c->max_ngen : c->max_nph;
+        const int sh_dim = metric == PC_POCP ? 2 * top + 1 : top + 1, tot_dim = 2 * top + 1;
         double* lut = nullptr; bool build_lut = false;
         if ((int64_t)sh_dim * tot_dim <= (4 << 20)) {
             if ((rc = c->b_lut.ensure((size_t)sh_dim * tot_dim * 8))) return rc == PC_ERR_NOMEM_INTERNAL ? PC_ERR_HIP : rc;
             lut = c->b_lut.as<double>();
-            const int64_t key = ((int64_t)metric << 40) | ((int64_t)as_distance << 32) | (int64_t)c->max_nph;
+            const int64_t key = ((int64_t)metric << 40) | ((int64_t)as_distance << 32) | (int64_t)top;
             build_lut = key != c->lut_key || lut != c->lut_ptr;
             c->lut_key = key; c->lut_ptr = lut;
         }
@@ -1185,7 +1210,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     } else if (metric == PC_POCP || metric == PC_AF) {
         // small matrices: the sparse tile kernel; large ones: the shared-pham walker (crossover measured at ~3,500 genomes;
         // PC_SET_KERNEL=walker|sparse forces one for A/B runs)
-        static const char* force = getenv("PC_SET_KERNEL");
+        const char* force = set_force;
         const bool walker = force ? !strcmp(force, "walker") : (int64_t)d.N * c->shard.nown > (int64_t)3500 * 3500;
         if (walker) {
             PcWalkArgs a; memset(&a, 0, sizeof(a));

@@ -26,6 +26,9 @@ struct PcDev {
     const int32_t* ent_gene;          // [E] first gene id (genes of an entry are consecutive)
     const int32_t* ent_pham;          // [E] pham id (ascending within a genome: the set bits of its bitmap row, in order)
     const uint32_t* ent_off;          // [N+1] entries of genome g = [ent_off[g], ent_off[g+1])
+    const uint32_t* para_off;         // [N+1] paralog entries of genome g (entries with more than one gene), ascending pham id:
+    const int32_t* para_pham;         // [..] their pham id
+    const int32_t* para_ex;           // [..] gene count - 1
     const int32_t* gene_len;          // [G]
     const int64_t* gene_off;          // [G] byte offset of the gene's codes (16-byte aligned)
     const uint8_t* codes;             // encoded residues, each gene padded to 16 B with PC_PADCODE

@@ -147,14 +147,47 @@ __device__ __forceinline__ void pc_stage_tile(const PcDev& d, const PcShard& sh,
 // ---------------------------------------------------------------------------------
 #define PWCH 32        // bitmap words staged per chunk
 
+// shared: |S n T| (gcs, jc) or the conserved gene count sum over shared phams of cnt_s + cnt_t (pocp); tot: nph_s + nph_t, resp. ngen_s + ngen_t
 template <int METRIC>
 __device__ __forceinline__ double pc_set_value(int shared, int tot, int as_distance) {
     double sim = 0.0;
     if (shared) {
         if (METRIC == PC_GCS) sim = (2.0 * (double)shared) / (double)tot;      // metrics.py:45-48
-        else sim = (double)shared / (double)(tot - shared);                     // metrics.py:75
+        else if (METRIC == PC_JC) sim = (double)shared / (double)(tot - shared);   // metrics.py:75
+        else sim = (double)shared / (double)tot;                                 // metrics.py:104-110
     }
     return pc_finish(sim, as_distance);
+}
+
+// pocp on the popcount kernels (r03).  conserved(s, t) = sum over shared phams of cnt_s + cnt_t = 2 |S n T| + the EXCESS
+// counts (cnt - 1) of the shared phams that are paralogs in s or in t -- and only ~6 % of a genome's entries are
+// paralogs.  So the kernel counts |S n T| exactly as for jc and, per staged chunk of bitmap words, lets the few paralog
+// entries (pham, cnt - 1; ascending pham, so a cursor per row walks them chunk by chunk) of the rows it holds test their
+// bit in the opposite rows (LDS) and add their excess.  ONLY >= 0: probe register-tile row ONLY alone (the word-split
+// kernel gives each wave one row of each side, so that the four waves do not walk the same lists four times).
+// (Staging the tile's lists in LDS first -- 12 packed entries per row, spill path for longer ones -- was built and measured
+// slower: N = 20,000 4.54 against 4.29 ms; what costs is the divergence of 16 different rows per wave, not the list reads.)
+struct PcParaRow { uint32_t cur, end; };
+template <int ROWSTEP, int LDW, int ONLY>
+__device__ __forceinline__ void pc_paralog_probe(const PcDev& d, PcParaRow (&st)[4], const uint64_t (*other)[LDW], int other0, int w0, int wn,
+                                                 int (&ex)[4][4], bool rows_are_first_index) {
+    const int p_end = (w0 + wn) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (ONLY >= 0 && i != ONLY) continue;
+        while (st[i].cur < st[i].end) {
+            const int p = d.para_pham[st[i].cur];
+            if (p >= p_end) break;
+            const int e = d.para_ex[st[i].cur];
+            ++st[i].cur;
+            const int w = (p >> 6) - w0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int hit = (int)((other[other0 + ROWSTEP * j][w] >> (p & 63)) & 1ULL);
+                if (rows_are_first_index) ex[i][j] += e * hit; else ex[j][i] += e * hit;
+            }
+        }
+    }
 }
 
 template <int METRIC>
@@ -162,8 +195,8 @@ __global__ void k_set_lut(double* __restrict__ lut, int sh_dim, int tot_dim, int
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sh_dim * tot_dim) return;
     const int tot = i / sh_dim, shared = i - tot * sh_dim;
-    // entries with shared > tot/2 (gcs) or shared > tot - shared (jc) never occur; keep them finite
-    const bool possible = 2 * shared <= tot;
+    // entries with shared > tot/2 (gcs) or shared > tot - shared (jc), conserved > total (pocp) never occur; keep them finite
+    const bool possible = METRIC == PC_POCP ? shared <= tot : 2 * shared <= tot;
     lut[i] = possible ? pc_set_value<METRIC>(shared, tot, as_distance) : 0.0;
 }
 
@@ -213,6 +246,24 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
     // the rows a thread reads: the slow index takes the tile's s rows under condensed output, its t rows otherwise
     uint64_t (*ra)[PWCH + 1] = condensed ? rs : rt;
     uint64_t (*rb)[PWCH + 1] = condensed ? rt : rs;
+    // pocp: the paralog lists of my 4 + 4 rows (rows outside the matrix have empty lists)
+    int ex[4][4];
+    PcParaRow st_a[4], st_b[4];
+    auto genome_of = [&](bool a_side, int local) {
+        if (a_side == (condensed != 0)) return s0 + local < d.N ? s0 + local : -1;                 // an s row
+        return k0 + local < sh.nown ? pc_owned(sh, k0 + local) : -1;                               // a t row
+    };
+    if (METRIC == PC_POCP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ex[i][j] = 0;
+            const int ga = genome_of(true, fy + 16 * i), gb = genome_of(false, fx + 16 * i);
+            st_a[i].cur = st_a[i].end = st_b[i].cur = st_b[i].end = 0;
+            if (ga >= 0) { st_a[i].cur = d.para_off[ga]; st_a[i].end = d.para_off[ga + 1]; }
+            if (gb >= 0) { st_b[i].cur = d.para_off[gb]; st_b[i].end = d.para_off[gb + 1]; }
+        }
+    }
     fetch(0);
     for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
         const int wn = min(PWCH, d.Wb - w0);
@@ -221,6 +272,10 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
         for (int p = 0; p < 8; ++p) { rs[r0 + 8 * p][wl] = vs[p]; rt[r0 + 8 * p][wl] = vt[p]; }
         __syncthreads();
         if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
+        if (METRIC == PC_POCP) {
+            pc_paralog_probe<16, PWCH + 1, -1>(d, st_a, rb, fx, w0, wn, ex, true);
+            pc_paralog_probe<16, PWCH + 1, -1>(d, st_b, ra, fy, w0, wn, ex, false);
+        }
         for (int w = 0; w < wn; ++w) {
             uint64_t a[4], b[4];
 #pragma unroll
@@ -248,7 +303,8 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
             if (s >= d.N || k >= sh.nown) continue;
             const int t = pc_owned(sh, k);
             if (s >= t) continue;
-            const int shared = acc[i][j], tot = d.nph[s] + d.nph[t];
+            const int shared = METRIC == PC_POCP ? 2 * acc[i][j] + ex[i][j] : acc[i][j];
+            const int tot = METRIC == PC_POCP ? d.ngen[s] + d.ngen[t] : d.nph[s] + d.nph[t];
             const double v = lut ? lut[tot * sh_dim + shared] : pc_set_value<METRIC>(shared, tot, as_distance);
             out[pc_out_index(d, sh, s, t, k, condensed)] = v;
         }
@@ -287,7 +343,8 @@ __global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, in
         fin_s[j] = s0 + ls; fin_k[j] = k0 + lt;
         const bool ok = fin_s[j] < d.N && fin_k[j] < sh.nown;
         fin_t[j] = ok ? pc_owned(sh, fin_k[j]) : 0;
-        fin_tot[j] = ok && fin_s[j] < fin_t[j] ? d.nph[fin_s[j]] + d.nph[fin_t[j]] : -1;     // -1: no such pair
+        fin_tot[j] = !(ok && fin_s[j] < fin_t[j]) ? -1                                          // -1: no such pair
+                     : METRIC == PC_POCP ? d.ngen[fin_s[j]] + d.ngen[fin_t[j]] : d.nph[fin_s[j]] + d.nph[fin_t[j]];
     }
     int acc[4][4];
 #pragma unroll
@@ -314,6 +371,27 @@ __global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, in
     };
     uint64_t (*ra)[PWCH + 1] = condensed ? rs : rt;
     uint64_t (*rb)[PWCH + 1] = condensed ? rt : rs;
+    // pocp: wave v probes register-tile row v of each side (all words of every chunk); the partial sums meet in LDS below
+    int ex[4][4];
+    PcParaRow st_a[4], st_b[4];
+    auto genome_of = [&](bool a_side, int local) {
+        if (a_side == (condensed != 0)) return s0 + local < d.N ? s0 + local : -1;
+        return k0 + local < sh.nown ? pc_owned(sh, k0 + local) : -1;
+    };
+    if (METRIC == PC_POCP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ex[i][j] = 0;
+            st_a[i].cur = st_a[i].end = st_b[i].cur = st_b[i].end = 0;
+        }
+        const int ga = genome_of(true, fy + 8 * wave), gb = genome_of(false, fx + 8 * wave);
+        PcParaRow ra_st = {0, 0}, rb_st = {0, 0};
+        if (ga >= 0) { ra_st.cur = d.para_off[ga]; ra_st.end = d.para_off[ga + 1]; }
+        if (gb >= 0) { rb_st.cur = d.para_off[gb]; rb_st.end = d.para_off[gb + 1]; }
+        if (wave == 0) { st_a[0] = ra_st; st_b[0] = rb_st; } else if (wave == 1) { st_a[1] = ra_st; st_b[1] = rb_st; }
+        else if (wave == 2) { st_a[2] = ra_st; st_b[2] = rb_st; } else { st_a[3] = ra_st; st_b[3] = rb_st; }
+    }
     fetch(0);
     for (int w0 = 0; w0 < d.Wb; w0 += PWCH) {
         const int wn = min(PWCH, d.Wb - w0);
@@ -322,6 +400,10 @@ __global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, in
         for (int p = 0; p < 4; ++p) { rs[r0 + 8 * p][wl] = vs[p]; rt[r0 + 8 * p][wl] = vt[p]; }
         __syncthreads();
         if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
+        if (METRIC == PC_POCP) {                                     // this wave's words of the chunk: wave, wave + 4, ...
+            pc_paralog_probe<8, PWCH + 1, -1>(d, st_a, rb, fx, w0, wn, ex, true);      // (the other three rows' lists are empty)
+            pc_paralog_probe<8, PWCH + 1, -1>(d, st_b, ra, fy, w0, wn, ex, false);
+        }
 #pragma unroll
         for (int q = 0; q < PWCH / 4; ++q) {
             const int w = wave + 4 * q;                              // wave-uniform
@@ -345,7 +427,7 @@ __global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, in
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(wave * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+        for (int j = 0; j < 4; ++j) part[(wave * 16 + i * 4 + j) * 64 + lane] = METRIC == PC_POCP ? 2 * acc[i][j] + ex[i][j] : acc[i][j];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -362,25 +444,32 @@ __global__ __launch_bounds__(256) void k_set_popc_ksplit(PcDev d, PcShard sh, in
 // word-split: N = 1,000 26.7 / 18.8 us, 2,000 53.6 / 35.8, 3,000 74.6 / 69.0, 5,000 157 / 167: gpurun_out r03_popc_exp2 -> profiles/)
 #define PC_SMALL_GRID_TILES 1536
 
+#define PC_SET_DISPATCH(KERNEL, GRID)                                                                                                       \
+    do {                                                                                                                                   \
+        if (metric == PC_GCS) hipLaunchKernelGGL(KERNEL<PC_GCS>, GRID, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);       \
+        else if (metric == PC_JC) hipLaunchKernelGGL(KERNEL<PC_JC>, GRID, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);  \
+        else hipLaunchKernelGGL(KERNEL<PC_POCP>, GRID, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);                     \
+    } while (0)
+
 int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_distance, double* out, int condensed,
                        double* lut, bool build_lut, int sh_dim, int tot_dim, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
     if (lut && build_lut) {
         const int n = sh_dim * tot_dim;
         if (metric == PC_GCS) hipLaunchKernelGGL(k_set_lut<PC_GCS>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
-        else hipLaunchKernelGGL(k_set_lut<PC_JC>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
+        else if (metric == PC_JC) hipLaunchKernelGGL(k_set_lut<PC_JC>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
+        else hipLaunchKernelGGL(k_set_lut<PC_POCP>, dim3((n + 255) / 256), dim3(256), 0, st, lut, sh_dim, tot_dim, as_distance);
     }
     const int64_t tiles64 = (int64_t)((d.N + 63) / 64) * ((sh.nown + 63) / 64);
-    static const int force = getenv("PC_POPC_TILE") ? atoi(getenv("PC_POPC_TILE")) : 0;    // tuning knob: 32 / 64
+    const char* force_env = getenv("PC_POPC_TILE");                                         // tuning / test knob: 32 / 64 (read per launch)
+    const int force = force_env ? atoi(force_env) : 0;
     const bool small = force ? force == 32 : tiles64 / 2 < PC_SMALL_GRID_TILES;             // about half of the tiles are live
     if (small) {
         dim3 grid(pc_tile_grid((d.N + 31) / 32, (sh.nown + 31) / 32));
-        if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc_ksplit<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
-        else hipLaunchKernelGGL(k_set_popc_ksplit<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+        PC_SET_DISPATCH(k_set_popc_ksplit, grid);
     } else {
         dim3 grid(pc_tile_grid((d.N + 63) / 64, (sh.nown + 63) / 64));
-        if (metric == PC_GCS) hipLaunchKernelGGL(k_set_popc<PC_GCS>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
-        else hipLaunchKernelGGL(k_set_popc<PC_JC>, grid, dim3(256), 0, st, d, sh, as_distance, out, condensed, (const double*)lut, sh_dim);
+        PC_SET_DISPATCH(k_set_popc, grid);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_set_popc launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }

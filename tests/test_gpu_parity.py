@@ -1155,3 +1155,51 @@ def test_borrowed_result_loan(gpu_ctx, native_built):
     gpu_ctx.upload(packed)
     with pytest.raises(hip.HipLibraryError):
         again.copy()
+
+
+def test_pocp_paralog_lists_spill_and_wide_entries(gpu_ctx, native_built):
+    """pocp on the popcount kernels: |S n T| from the popcount, plus the excess gene counts of the shared PARALOG phams from
+    per-genome paralog lists (metrics.py:102-110).  Genomes with none, with dozens of paralog phams, and with thousands of
+    copies of one pham, against the oracle, through both tile kernels, unsharded and as a shard."""
+    import torch
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(3)
+    genomes = []
+    for k in range(70):
+        g = Genome(f"g{k:03d}")
+        n_para = int(rng.integers(0, 30)) if k % 3 else 0              # up to 29 paralog phams: well past the 12 staged
+        phams = rng.choice(300, size=int(rng.integers(20, 60)), replace=False)
+        for idx, p in enumerate(sorted(phams)):
+            copies = int(rng.integers(2, 5)) if idx < n_para else 1
+            if k == 7 and idx == 0:
+                copies = 4200                                           # excess 4,199 does not fit the packed entry
+            for _ in range(copies):
+                g.add(f"p{p:04d}", "MK")
+        genomes.append(g)
+    packed = pack_genomes(genomes)
+    want = O.fill(packed, "pocp")
+    try:
+        for tile in ("32", "64"):
+            os.environ["PC_POPC_TILE"] = tile                           # the launcher reads the knob per launch
+            gpu_ctx.upload(packed, residues=False)
+            assert np.array_equal(gpu_ctx.fill("pocp"), want), tile
+            assert np.array_equal(gpu_ctx.fill("jc"), O.fill(packed, "jc")), tile
+    finally:
+        os.environ.pop("PC_POPC_TILE", None)
+    gpu_ctx.set_shard(1, 3)
+    stride = gpu_ctx.shard_stride()
+    buf = torch.full((stride,), -1.0, dtype=torch.float64, device="cuda:0")
+    gpu_ctx.fill_shard_dev("pocp", True, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t_rank, t_lbase = gpu_ctx.shard_table()
+    got = buf.cpu().numpy()
+    n = packed.n_genomes
+    for t in range(1, n):
+        if t_rank[t] != 1:
+            continue
+        s = np.arange(t)
+        cond = s * n - s * (s + 1) // 2 + (t - s - 1)
+        assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], want[cond])
+    gpu_ctx.set_shard(0, 1)
