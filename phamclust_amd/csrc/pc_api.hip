@@ -385,7 +385,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
                 if (len < 0 || len > 65535) { over[0] = (int)k; gene_len[k] = 0; } else gene_len[k] = (int32_t)len;   // (racy write of ONE reported index: any offender will do)
                 gene_len_h[k] = gene_len[k];
             }
-        });
+        }, 65536);                                                   // (a thread costs ~30 us to start: few of them for small inputs)
         if (over[0] >= 0) {
             const int k = over[0];
             pc_set_error("pc_upload: gene %d has length %lld (limit 65535)", k, (long long)(g->seq_off[k + 1] - g->seq_off[k])); return PC_ERR_LIMIT;
@@ -408,7 +408,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
             for (int w = 0; w < W; ++w) bits += (size_t)__builtin_popcountll(row[w]);
             ent_off[(size_t)s + 1] = (uint32_t)bits;
         }
-    }, 64);
+    }, 1024);
     for (int s = 0; s < N; ++s) ent_off[(size_t)s + 1] += ent_off[s];
     const size_t E = ent_off[N];
     if (E > (size_t)G) { pc_set_error("pc_upload: the bitmap holds more phams than there are genes"); return PC_ERR_ARG; }
@@ -437,7 +437,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
             if (!err && (ne != cap || (int)ne != g->nph[s] || (int)(k1 - k0) != g->ngen[s] || tl != g->tlen[s])) err = 2;
             bad[s] = err;
         }
-    }, 64);
+    }, 512);
     for (int s = 0; s < N; ++s) {
         if (bad[s] == 1) { pc_set_error("pc_upload: genome %d: a gene's pham id is out of order or not in the bitmap", s); return PC_ERR_ARG; }
         if (bad[s] == 2) { pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG; }

@@ -51,15 +51,16 @@ def test_oracle_c_equals_python_restatement_and_metric_identities(O, dicts):
                 assert sim[m][k] == O.PY_METRICS[m](genomes[i], genomes[j], as_distance=False), m
             for m in ("gcs", "jc", "pocp", "af"):
                 assert O.PY_METRICS[m](genomes[j], genomes[i]) == sim[m][k], m
-            assert sim["peq"][k] == round(sim["af"][k] * sim["aai"][k], 6)
+            # (Python floats: numpy's float64.__round__ is rint(x * 1e6) / 1e6, not CPython's correctly rounded round())
+            assert sim["peq"][k] == round(float(sim["af"][k]) * float(sim["aai"][k]), 6)
             assert (sim["gcs"][k] == 0.0) == (sim["jc"][k] == 0.0) == (sim["pocp"][k] == 0.0)
             assert 0.0 <= sim["jc"][k] <= sim["gcs"][k] <= 1.0
             k += 1
     for g in genomes:
         for m in ("gcs", "jc", "pocp", "af", "aai", "peq"):
             assert O.PY_METRICS[m](g, g) == 1.0, m
-    dist = O.fill(packed, "peq", as_distance=True)
-    assert np.array_equal(dist, np.array([round(1.0 - x, 6) for x in sim["peq"]]))
+    dist = O.fill(packed, "peq", as_distance=True)                      # metrics.py:250-253: 1 - af * aai of the two ROUNDED factors, rounded once
+    assert np.array_equal(dist, np.array([round(1.0 - float(a) * float(b), 6) for a, b in zip(sim["af"], sim["aai"])]))
 
 
 @settings(**SETTINGS)
