@@ -3,7 +3,10 @@
 sequences, odd residues, tie-heavy 3-letter sequences, lengths up to 1,500), every collection under a randomly chosen
 row of the tie-rule table (kernel and oracle switched together): `python tools/stress_random.py SEED TRIALS`.
 r01: seed 4242, 1,500 collections, 9,000 fills, 0 mismatches; seed 20261004, 4,000 collections, 24,000 fills, 0 mismatches.
-r02 (64-bit lexicographic-max cell, all 8 rules): see profiles/r02_stress.txt."""
+r02 (64-bit lexicographic-max cell, all 8 rules): see profiles/r02_stress.txt.
+r03: every collection additionally draws a plan budget (aai / peq fills in one piece or in many chunks), a two-part or a full
+upload, both popcount tile kernels (PC_POPC_TILE, read per launch) and, every fourth one, a shard of a 2- or 3-rank deal compared with
+the same pairs of the unsharded matrix: see profiles/r03_stress.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -35,12 +38,32 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
                 genome.add(f"pham{p}", seq)
         genomes.append(genome)
     packed = pack_genomes(genomes)
-    ctx.upload(packed)
+    ctx.upload(packed, residues=bool(rng.random() < 0.5))              # two-part upload: the residues follow on demand
+    ctx.set_plan_budget(int(rng.choice([0, 56, 56 * 7, 56 * 60, 56 * 2000])))   # 0: automatic; tiny: one target genome per chunk
+    os.environ["PC_POPC_TILE"] = str(rng.choice(["32", "64"]))
     for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
         got = ctx.fill(metric, as_distance=bool(trial & 1))
         want = O.fill(packed, metric, as_distance=bool(trial & 1))
         if not np.array_equal(got, want):
             bad += 1; print("MISMATCH", trial, metric, "rule", rule, flush=True)
+    if trial % 4 == 3 and n_genomes >= 3:                               # a shard of a multi-rank deal == the same pairs of the matrix
+        import torch
+        world = int(rng.integers(2, 4)); rank = int(rng.integers(0, world)); metric = str(rng.choice(["jc", "pocp", "af", "peq"]))
+        want = ctx.fill(metric, as_distance=True)
+        ctx.set_shard(rank, world, balanced=bool(rng.random() < 0.5))
+        stride = ctx.shard_stride()
+        buf = torch.full((max(stride, 1),), -1.0, dtype=torch.float64, device="cuda:0")
+        ctx.fill_shard_dev(metric, True, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        t_rank, t_lbase = ctx.shard_table()
+        got = buf.cpu().numpy()
+        n = packed.n_genomes
+        for t in range(1, n):
+            if t_rank[t] == rank:
+                s_idx = np.arange(t)
+                if not np.array_equal(got[t_lbase[t]:t_lbase[t] + t], want[s_idx * n - s_idx * (s_idx + 1) // 2 + (t - s_idx - 1)]):
+                    bad += 1; print("SHARD MISMATCH", trial, metric, rank, world, flush=True); break
+        ctx.set_shard(0, 1)
     if trial % 100 == 99: print("trial", trial + 1, "mismatches", bad, flush=True)
 print("done, mismatches", bad)
 sys.exit(1 if bad else 0)
