@@ -534,7 +534,8 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     // beyond that the residues go over from the caller's pageable memory at the end), and the DMA to HBM is started as soon as
     // they are done: it runs behind the de-duplication and the launch-class tables below.
     const int64_t raw_bytes = g->seq_off[G] - g->seq_off[0];
-    const bool staged = raw_bytes > 0 && raw_bytes <= ((int64_t)512 << 20);
+    static const int64_t stage_max = getenv("PC_RAW_STAGE_MAX") ? atoll(getenv("PC_RAW_STAGE_MAX")) : ((int64_t)512 << 20);   // (test knob)
+    const bool staged = raw_bytes > 0 && raw_bytes <= stage_max;
     if (staged && (size_t)raw_bytes > c->h_raw_cap) {
         if (c->h_raw) { (void)hipHostFree(c->h_raw); c->h_raw = nullptr; c->h_raw_cap = 0; }
         const size_t want = (size_t)raw_bytes + (size_t)raw_bytes / 8;
@@ -573,19 +574,38 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     // sequences grouped by the kernel variant that aligns against them and by lanes-per-segment bucket (the
     // profile's LDS footprint scales with it, and LDS sets occupancy)
     std::vector<int32_t> uid(G), u_gene;
-    {   // open-addressing table over the precomputed hashes; equal hash and length are confirmed by comparing the residues
-        size_t cap = 16;
-        while (cap < (size_t)G * 2) cap <<= 1;
-        std::vector<int32_t> slot(cap, -1);
-        for (int k = 0; k < G; ++k) {
-            size_t pos = (size_t)ghash[k] & (cap - 1);
-            for (;; pos = (pos + 1) & (cap - 1)) {
-                const int32_t u = slot[pos];
-                if (u < 0) { slot[pos] = (int32_t)u_gene.size(); uid[k] = (int32_t)u_gene.size(); u_gene.push_back(k); break; }
-                const int r = u_gene[u];
-                if (ghash[r] == ghash[k] && gene_len[r] == gene_len[k] &&
-                    !memcmp(raw + g->seq_off[r], raw + g->seq_off[k], (size_t)gene_len[k])) { uid[k] = u; break; }
+    {   // Representative of a gene = the first gene with the same residues.  Sixteen hash partitions, one thread and one
+        // open-addressing table each (every thread scans all hashes and takes its own: genes arrive in index order, so the first
+        // one in is the first occurrence); equal hash and length are confirmed by comparing the residues.  Sequence ids then
+        // follow first-occurrence order, exactly as a single serial table would number them.
+        constexpr int NPART = 16;
+        std::vector<int32_t> rep(G);
+        std::vector<std::thread> th;
+        const int nthreads = G >= 32768 ? NPART : 1;
+        auto work = [&](int part, int nparts) {
+            size_t cap = 16;
+            while (cap < (size_t)G * 2 / (size_t)nparts + 16) cap <<= 1;
+            std::vector<int32_t> slot(cap, -1);
+            for (int k = 0; k < G; ++k) {
+                if (nparts > 1 && (int)((ghash[k] >> 40) & (NPART - 1)) != part) continue;
+                size_t pos = (size_t)ghash[k] & (cap - 1);
+                for (;; pos = (pos + 1) & (cap - 1)) {
+                    const int32_t r = slot[pos];
+                    if (r < 0) { slot[pos] = k; rep[k] = k; break; }
+                    if (ghash[r] == ghash[k] && gene_len[r] == gene_len[k] &&
+                        !memcmp(raw + g->seq_off[r], raw + g->seq_off[k], (size_t)gene_len[k])) { rep[k] = r; break; }
+                }
             }
+        };
+        if (nthreads == 1) work(0, 1);
+        else {
+            for (int t = 0; t < NPART; ++t) th.emplace_back(work, t, NPART);
+            for (auto& x : th) x.join();
+        }
+        u_gene.reserve(G);
+        for (int k = 0; k < G; ++k) {
+            if (rep[k] == k) { uid[k] = (int32_t)u_gene.size(); u_gene.push_back(k); }
+            else uid[k] = uid[rep[k]];
         }
     }
     const int U = (int)u_gene.size();
@@ -618,21 +638,25 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     c->cls_max_lb.assign(ncls_all, 0);
     for (int len = 0; len <= maxlen; ++len) if (len_cls[len] >= 0) c->cls_max_lb[len_cls[len]] = std::max(c->cls_max_lb[len_cls[len]], len);
     for (int u = 0; u < U; ++u) if (godd[u_gene[u]]) c->cls_max_lb[u_cls[u]] = std::max(c->cls_max_lb[u_cls[u]], (int)gene_len[u_gene[u]]);
-    for (int len = 1; len <= maxlen; ++len) {
-        const int v = len_var[len];
-        if (len_cls[len] < 0 || v < 0) continue;
-        const int Wv = pc_nw_variant_w(v), Gv = (len + Wv - 1) / Wv;
-        const int nseg = std::min(64 / Gv, 16);
-        len_nseg[len] = (uint8_t)nseg;
-        for (int r = 1; r < nseg; ++r) {
-            const int vr = pc_nw_choose_remainder(len, r, v);
-            if (vr >= 0) {
-                const int cr = pc_class_of(len, vr, false);
-                len_rem[(size_t)len * 16 + r] = (uint8_t)cr;
-                c->cls_max_lb[cr] = std::max(c->cls_max_lb[cr], len);
+    // (the remainder chooser is a cost model evaluated ~15 times per distinct length: several threads, then the class maxima)
+    parallel_chunks(maxlen, [&](int64_t l0, int64_t l1) {
+        for (int64_t len = l0 + 1; len <= l1; ++len) {
+            const int v = len_var[len];
+            if (len_cls[len] < 0 || v < 0) continue;
+            const int Wv = pc_nw_variant_w(v), Gv = ((int)len + Wv - 1) / Wv;
+            const int nseg = std::min(64 / Gv, 16);
+            len_nseg[len] = (uint8_t)nseg;
+            for (int r = 1; r < nseg; ++r) {
+                const int vr = pc_nw_choose_remainder((int)len, r, v);
+                if (vr >= 0) len_rem[(size_t)len * 16 + r] = (uint8_t)pc_class_of((int)len, vr, false);
             }
         }
-    }
+    }, 64);
+    for (int len = 1; len <= maxlen; ++len)
+        for (int r = 1; r < 16; ++r) {
+            const uint8_t cr = len_rem[(size_t)len * 16 + r];
+            if (cr != 255) c->cls_max_lb[cr] = std::max(c->cls_max_lb[cr], len);
+        }
     // ranks inside a class follow sequence length (then first occurrence): the plan's sort then hands every bucket its
     // rows in length order, so the row streams of a task, dealt round-robin, stay in step and start their alignments
     // in the same steps (the per-step cost of an alignment start is paid once per wave, not once per segment; measured

@@ -1203,3 +1203,26 @@ def test_pocp_paralog_lists_spill_and_wide_entries(gpu_ctx, native_built):
         cond = s * n - s * (s + 1) // 2 + (t - s - 1)
         assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], want[cond])
     gpu_ctx.set_shard(0, 1)
+
+
+def test_upload_without_page_locked_staging(native_built):
+    """pc_upload stages the raw residues through page-locked memory up to 512 MB and sends larger inputs from the caller's
+    pageable buffer; PC_RAW_STAGE_MAX=0 forces that second route (own process: the knob is read once)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from phamclust_amd import hip
+from phamclust_amd.synth import synth_packed
+from oracle import oracle as O
+pk = synth_packed(150, 800, seed=8)
+with hip.Context(0) as ctx:
+    ctx.upload(pk)
+    assert np.array_equal(ctx.fill("peq"), O.fill(pk, "peq"))
+    ctx.upload(pk, residues=False)
+    assert np.array_equal(ctx.fill("aai"), O.fill(pk, "aai"))
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_RAW_STAGE_MAX="0"), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
