@@ -28,7 +28,10 @@ Extra objects on that line:
                 this host on a bounded sample of the same workload (leading matrix rows), on
                 every core the process may use, plus a one-thread sample.
   wall_ms_incl_upload_d2h   SURVEY 8(d)'s wall time of one matrix: upload of the packed genomes
-                + kernels + D2H of the condensed vector (never `value`).
+                + kernels + D2H of the condensed vector (never `value`); `value_wall` = pairs / that.
+  stage_ms      N = 1: plan / align / reduce of one fill (HIP events inside the library).  N > 1: per-rank
+                stages as max over ranks, the exchange (gather or reduce) and the root-only assembly as rank 0
+                sees them, `shards` (pairs / cells min-max over ranks), `config.dist_mode`.
 Exit status 1 (and "valid": false) when the sampled oracle check is not bit-exact.
 """
 

@@ -146,7 +146,7 @@ struct pc_ctx {
     DevBuf b_sets;                          // part 1 of the upload, one allocation: bitmap | rank table | gene lengths | entry offsets | nph | ngen | tlen | 4 entry arrays
     uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;   // its page-locked host image (grow-only)
     uint8_t* h_raw = nullptr; size_t h_raw_cap = 0;       // page-locked staging of the raw residues (part 2; grow-only, <= 512 MB)
-    DevBuf b_bitmap, b_rankpre, b_ent_cnt, b_ent_len, b_ent_gene, b_gene_len, b_gene_off, b_codes, b_nph, b_ngen, b_tlen;
+    DevBuf b_gene_off, b_codes;
     DevBuf b_gene_q, b_q_gene, b_q_class, b_q_nseg, b_rem_class, b_cls_begin, b_task_rows, b_owned, b_lbase, b_t_rank, b_t_lbase, b_cost;
     // work buffers (grow-only)
     DevBuf b_na, b_off, b_key0, b_key1, b_val0, b_val1, b_sort_tmp, b_flags, b_excl, b_alias, b_start_q, b_end_q, b_ntask_q, b_task_off_q, b_scan_tmp;
@@ -246,8 +246,8 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
-    DevBuf* bufs[] = {&c->b_raw, &c->b_seq_tmp, &c->b_sets, &c->b_bitmap, &c->b_rankpre, &c->b_ent_cnt, &c->b_ent_len, &c->b_ent_gene, &c->b_gene_len, &c->b_gene_off,
-                      &c->b_codes, &c->b_nph, &c->b_ngen, &c->b_tlen, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
+    DevBuf* bufs[] = {&c->b_raw, &c->b_seq_tmp, &c->b_sets, &c->b_gene_off,
+                      &c->b_codes, &c->b_gene_q, &c->b_q_gene, &c->b_q_class, &c->b_q_nseg, &c->b_rem_class, &c->b_cls_begin, &c->b_task_rows, &c->b_owned, &c->b_lbase, &c->b_t_rank, &c->b_t_lbase, &c->b_cost,
                       &c->b_na, &c->b_off, &c->b_key0, &c->b_key1, &c->b_val0, &c->b_val1, &c->b_sort_tmp, &c->b_flags, &c->b_excl, &c->b_alias,
                       &c->b_start_q, &c->b_end_q,
                       &c->b_ntask_q, &c->b_task_off_q, &c->b_scan_tmp, &c->b_tasks, &c->b_tasks_sorted, &c->b_bucket_row, &c->b_bucket_dest,
