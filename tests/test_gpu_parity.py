@@ -1062,7 +1062,7 @@ sys.path.insert(0, %r)
 from phamclust_amd import hip
 from phamclust_amd.synth import synth_packed
 from oracle import oracle as O
-pk = synth_packed(400, 2000, seed=3)
+pk = synth_packed(260, 1500, seed=3)
 with hip.Context(0) as ctx:
     ctx.upload(pk)
     got, st = ctx.fill("peq", want_stats=True)
@@ -1070,7 +1070,7 @@ with hip.Context(0) as ctx:
     assert np.array_equal(got, O.fill(pk, "peq")), "chunked-after-OOM fill differs from the oracle"
     print("chunks", st["n_chunks"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 20))       # ~0.25 M alignments: the one-piece plan's A * 8-byte buffers are ~2 MB
+    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19))       # ~0.1 M alignments: the one-piece plan's A * 8-byte buffers are ~0.9 MB
     run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "chunks" in run.stdout
@@ -1109,10 +1109,10 @@ def test_unsynchronised_slice_survives_reupload(gpu_ctx, native_built):
     import torch
     from phamclust_amd.synth import synth_packed
     O = _oracle()
-    a_pk, b_pk = synth_packed(260, 900, seed=51), synth_packed(70, 400, seed=52)
+    a_pk, b_pk = synth_packed(150, 700, seed=51), synth_packed(60, 400, seed=52)
     want_a, want_b = O.fill(a_pk, "peq"), O.fill(b_pk, "peq")
     side = torch.cuda.Stream()
-    for _ in range(3):
+    for _ in range(2):
         gpu_ctx.upload(a_pk)
         plan = gpu_ctx.plan_dev("peq", side.cuda_stream)
         n = plan["n_distinct_alignments"]
