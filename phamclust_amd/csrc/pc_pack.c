@@ -249,6 +249,9 @@ int64_t pcp_genome_fasta(const pcp_data* d, int32_t g, char* out, int64_t cap) {
  * ------------------------------------------------------------------------------------- */
 #include <math.h>
 
+/* the longest "%.6f" of a double: 1 sign + 309 digits + '.' + 6 decimals (+ NUL) */
+#define PCP_FMT_MAX 320
+
 /* "%.6f" of one double.  Fast path: |x| < 1e9 and x*1e6 is within 0.49 of an integer k that the product cannot
  * mis-round (the product's rounding error is ~1e-10 relative) -> print k as d.dddddd; anything else goes
  * through snprintf, so the bytes are always those of "%.6f". */
@@ -266,13 +269,19 @@ static char* fmt6(double x, char* p) {
             return p;
         }
     }
-    return p + snprintf(p, 400, "%.6f", x);
+    return p + snprintf(p, PCP_FMT_MAX, "%.6f", x);
 }
 
-/* values joined by tabs, terminated by '\n'; returns bytes written (out must hold 24 bytes per value + 400) */
-int64_t pcp_format_row(const double* v, int64_t n, char* out) {
-    char* p = out;
-    for (int64_t i = 0; i < n; ++i) { if (i) *p++ = '\t'; p = fmt6(v[i], p); }
+/* values joined by tabs, terminated by '\n'; returns bytes written, or -1 when `cap` bytes cannot hold them (a value in
+ * [0, 1] takes 8 bytes; the check is made before every value against the longest a double can take) */
+int64_t pcp_format_row(const double* v, int64_t n, char* out, int64_t cap) {
+    char* p = out; char* const end = out + cap;
+    for (int64_t i = 0; i < n; ++i) {
+        if (end - p < PCP_FMT_MAX + 2) return -1;
+        if (i) *p++ = '\t';
+        p = fmt6(v[i], p);
+    }
+    if (end - p < 1) return -1;
     *p++ = '\n';
     return (int64_t)(p - out);
 }
@@ -280,12 +289,13 @@ int64_t pcp_format_row(const double* v, int64_t n, char* out) {
 /* adjacency lines "source<TAB>target<TAB>value\n" for targets j0..n-1 of one source row (reference matrix.py
  * matrix_to_adjacency); names: concatenated UTF-8, name_off[n+1].  skip_zero drops values equal to 0. */
 int64_t pcp_format_adjacency(const char* src, int64_t src_len, const char* names, const int64_t* name_off, const double* row,
-                             int64_t j0, int64_t n, int skip_zero, char* out) {
-    char* p = out;
+                             int64_t j0, int64_t n, int skip_zero, char* out, int64_t cap) {
+    char* p = out; char* const end = out + cap;
     for (int64_t j = j0; j < n; ++j) {
         if (skip_zero && row[j] == 0.0) continue;
-        memcpy(p, src, (size_t)src_len); p += src_len; *p++ = '\t';
         const int64_t len = name_off[j + 1] - name_off[j];
+        if (end - p < src_len + len + PCP_FMT_MAX + 3) return -1;
+        memcpy(p, src, (size_t)src_len); p += src_len; *p++ = '\t';
         memcpy(p, names + name_off[j], (size_t)len); p += len; *p++ = '\t';
         p = fmt6(row[j], p); *p++ = '\n';
     }

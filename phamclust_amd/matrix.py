@@ -438,10 +438,10 @@ def _text_lib():
         try:
             lib = ctypes.CDLL(path)
             lib.pcp_format_row.restype = ctypes.c_int64
-            lib.pcp_format_row.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
+            lib.pcp_format_row.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]
             lib.pcp_format_adjacency.restype = ctypes.c_int64
             lib.pcp_format_adjacency.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p]
+                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64]
             lib.pcp_parse_row.restype = ctypes.c_int64
             lib.pcp_parse_row.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
             _TEXT_LIB = lib
@@ -467,12 +467,15 @@ def matrix_to_adjacency(matrix, filepath, skip_zero=False):
     np.cumsum([len(x) for x in names], out=offsets[1:])
     n = len(names)
     width = (max((len(x) for x in names), default=0)) * 2 + 32
-    buf = ctypes.create_string_buffer(n * width + 512)
+    cap = n * width + 1024
+    buf = ctypes.create_string_buffer(cap)
     data = np.ascontiguousarray(data, dtype=np.float64)
     with open(filepath, "wb") as handle:
         for i, source in enumerate(names):
             size = lib.pcp_format_adjacency(source, len(source), blob, offsets.ctypes.data, data[i].ctypes.data, i, n,
-                                            1 if skip_zero else 0, buf)
+                                            1 if skip_zero else 0, buf, cap)
+            if size < 0:
+                raise ValueError(f"{filepath}: a row of '{source.decode()}' does not fit its buffer (weights outside [0, 1]?)")
             handle.write(buf.raw[:size] if size < 65536 else memoryview(buf)[:size])
     return filepath
 
@@ -541,14 +544,17 @@ def matrix_to_squareform(matrix, filepath, lower_triangle=False):
     import ctypes
     n = len(matrix)
     data = np.ascontiguousarray(data, dtype=np.float64)
-    buf = ctypes.create_string_buffer(n * 24 + 512)
+    cap = n * 24 + 1024
+    buf = ctypes.create_string_buffer(cap)
     with open(filepath, "wb") as handle:
         header = f"{n}"
         if not lower_triangle:
             header += "\t" + "\t".join(matrix.nodes)
         handle.write(f"{header}\n".encode())
         for i, source in enumerate(matrix.nodes):
-            size = lib.pcp_format_row(data[i].ctypes.data, i + 1 if lower_triangle else n, buf)
+            size = lib.pcp_format_row(data[i].ctypes.data, i + 1 if lower_triangle else n, buf, cap)
+            if size < 0:
+                raise ValueError(f"{filepath}: the row of '{source}' does not fit its buffer (weights outside [0, 1]?)")
             handle.write(source.encode() + b"\t")
             handle.write(memoryview(buf)[:size])
     return filepath

@@ -69,6 +69,19 @@ for n in (1, 2, 3, 17, 130):
             assert np.array_equal(back.extract_submatrix(names).to_ndarray(), m.to_ndarray())
 lib = M._text_lib()
 import ctypes                                                                 # noqa: E402
+# the formatters never write past `cap`, whatever the doubles (a value outside [0, 1] can take 317 bytes instead of 8)
+wild = np.array([0.0, 1.0, -0.0, 0.123456789, 1e300, -1e300, 1e-300, np.inf, -np.inf, np.nan, 5e-7, 123456789.5, 2 ** 63, -2.5], dtype=np.float64)
+for cap in (1, 8, 100, 321, 322, 323, 400, 1000, 5000, 10000):
+    buf = ctypes.create_string_buffer(cap)
+    for n in (0, 1, 2, 7, 14):
+        got = lib.pcp_format_row(wild.ctypes.data, n, buf, cap)
+        assert got == -1 or (0 < got <= cap and buf.raw[got - 1:got] == b"\n")
+        if got > 0:
+            assert buf.raw[:got].decode() == "\t".join("%.6f" % x for x in wild[:n]) + "\n"
+    names_blob = b"alpha" + b"b" * 300 + b"c"
+    offs = np.array([0, 5, 305, 306] + [306] * 12, dtype=np.int64)
+    got = lib.pcp_format_adjacency(b"src", 3, names_blob, offs.ctypes.data, wild.ctypes.data, 0, 3, 0, buf, cap)
+    assert got == -1 or 0 < got <= cap
 for text in (b"", b"0.5", b"0.5\t", b"\t", b"abc", b"1e309\t-0.0\tnan", b"0.1\t0.2\t0.3\t0.4", b"1" * 5000, b"0.25\t" * 999 + b"0.5",
              b"\x00\x01\x02", b"0.5\x000.7", b" 0.5 \t 0.7 "):
     for cap in (0, 1, 3, 1000):

@@ -290,8 +290,10 @@ def test_text_io_c_path_is_byte_identical(native_built, tmp_path):
     special = np.array([0.0, 1.0, 0.5, 1e-7, 4.9999999e-7, 5e-7, 5.0000001e-7, 0.9999995, 0.99999949, 0.1234565, 0.1234575,
                         2.5e-6, 3.5e-6, 123456.7890125, -0.0, -1e-9, -0.25, 1e8, 0.000001, 0.999999])
     values = np.concatenate([special, rng.random(5000), np.round(rng.random(5000), 6), rng.random(200) * 1e-6])
-    buf = ctypes.create_string_buffer(values.size * 24 + 512)
-    size = lib.pcp_format_row(values.ctypes.data, values.size, buf)
+    cap = values.size * 24 + 1024
+    buf = ctypes.create_string_buffer(cap)
+    size = lib.pcp_format_row(values.ctypes.data, values.size, buf, cap)
+    assert lib.pcp_format_row(values.ctypes.data, values.size, buf, 4000) == -1          # a buffer that cannot hold the row is refused, not overrun
     assert buf.raw[:size] == ("\t".join(f"{x:.6f}" for x in values.tolist()) + "\n").encode()
     back = np.empty(values.size)
     assert lib.pcp_parse_row(buf.raw[:size - 1], size - 1, back.ctypes.data, values.size) == values.size
