@@ -108,6 +108,7 @@ pcp_data* pcp_load_tsv(const char* path) {
     int64_t sg_cap = 1 << 12, sp_cap = 1 << 14; int32_t n_g = 0, n_p = 0;
     str_t* gnames = (str_t*)malloc((size_t)sg_cap * sizeof(str_t));
     str_t* pnames = (str_t*)malloc((size_t)sp_cap * sizeof(str_t));
+    if (!genes || !gnames || !pnames) { free(genes); free(gnames); free(pnames); map_free(&gmap); map_free(&pmap); return fail(d, "out of memory", -1); }
     static const char M[] = "M";
     int64_t lineno = 0;
     for (char* p = d->file; p < d->file + size;) {
@@ -117,17 +118,23 @@ pcp_data* pcp_load_tsv(const char* path) {
         char* q = e;
         while (q > p && (q[-1] == ' ' || q[-1] == '\t' || q[-1] == '\r' || q[-1] == '\n' || q[-1] == '\v' || q[-1] == '\f')) --q;
         str_t col[3]; int nc = 0; char* s = p;
+        int too_long = 0;
         for (char* c = p; c <= q; ++c) {
-            if (c == q || *c == '\t') { if (nc < 3) { col[nc].p = s; col[nc].len = (int32_t)(c - s); } ++nc; s = c + 1; }
+            if (c == q || *c == '\t') {
+                if (nc < 3) { col[nc].p = s; col[nc].len = (int32_t)(c - s); if (c - s > 0x7fffffff) too_long = 1; }
+                ++nc; s = c + 1;
+            }
         }
+        if (too_long) { free(genes); free(gnames); free(pnames); map_free(&gmap); map_free(&pmap); return fail(d, "a field is longer than 2^31-1 bytes", lineno); }
         if (nc != 2 && nc != 3) { free(genes); free(gnames); free(pnames); map_free(&gmap); map_free(&pmap); return fail(d, "input file must either 2 or 3 columns", lineno); }
         if (nc == 2) { col[2].p = M; col[2].len = 1; }
         int is_new;
         int32_t gi = map_get(&gmap, col[0].p, col[0].len, n_g, &is_new);
-        if (is_new) { if (n_g >= sg_cap) { sg_cap *= 2; gnames = (str_t*)realloc(gnames, (size_t)sg_cap * sizeof(str_t)); } gnames[n_g++] = col[0]; }
-        int32_t pi = map_get(&pmap, col[1].p, col[1].len, n_p, &is_new);
-        if (is_new) { if (n_p >= sp_cap) { sp_cap *= 2; pnames = (str_t*)realloc(pnames, (size_t)sp_cap * sizeof(str_t)); } pnames[n_p++] = col[1]; }
-        if (ng >= gcap) { gcap *= 2; genes = (gene_t*)realloc(genes, (size_t)gcap * sizeof(gene_t)); }
+        if (gi >= 0 && is_new) { if (n_g >= sg_cap) { sg_cap *= 2; void* nb = realloc(gnames, (size_t)sg_cap * sizeof(str_t)); if (!nb) gi = -1; else gnames = (str_t*)nb; } if (gi >= 0) gnames[n_g++] = col[0]; }
+        int32_t pi = gi < 0 ? -1 : map_get(&pmap, col[1].p, col[1].len, n_p, &is_new);
+        if (pi >= 0 && is_new) { if (n_p >= sp_cap) { sp_cap *= 2; void* nb = realloc(pnames, (size_t)sp_cap * sizeof(str_t)); if (!nb) pi = -1; else pnames = (str_t*)nb; } if (pi >= 0) pnames[n_p++] = col[1]; }
+        if (pi >= 0 && ng >= gcap) { gcap *= 2; void* nb = realloc(genes, (size_t)gcap * sizeof(gene_t)); if (!nb) pi = -1; else genes = (gene_t*)nb; }
+        if (gi < 0 || pi < 0) { free(genes); free(gnames); free(pnames); map_free(&gmap); map_free(&pmap); return fail(d, "out of memory", lineno); }
         genes[ng].genome = gi; genes[ng].pham = pi; genes[ng].order = ng; genes[ng].seq = col[2]; ++ng;
         p = e + 1;
     }
