@@ -910,11 +910,11 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
 // written); returns the number of ranges.
 extern "C" int pc_chunk_plan(const uint64_t* count, int n, uint64_t max_per_chunk, int32_t* chunk_begin, int cap) {
     if (!count || n < 0 || max_per_chunk == 0) { pc_set_error("pc_chunk_plan: bad argument"); return PC_ERR_ARG; }
-    int nch = 0; uint64_t run = 0;
+    int nch = 0, start = 0; uint64_t run = 0;
     auto put = [&](int v) { if (chunk_begin && nch < cap) chunk_begin[nch] = v; ++nch; };
     if (n > 0) put(0);
-    for (int k = 0; k < n; ++k) {
-        if (run > 0 && (run + count[k] > max_per_chunk || run + count[k] < run)) { put(k); run = 0; }
+    for (int k = 0; k < n; ++k) {                      // (the same rule as fill_aligned's loop: extend while the sum stays within the limit)
+        if (k > start && (run + count[k] > max_per_chunk || run + count[k] < run)) { put(k); run = 0; start = k; }
         run += count[k];
     }
     if (chunk_begin && nch < cap) chunk_begin[nch] = n;
