@@ -11,7 +11,7 @@ AA = "ACDEFGHIKLMNPQRSTVWY"
 seqs = st.text(alphabet=AA + "BZX*acdJU", min_size=1, max_size=40)
 few_letter_seqs = st.text(alphabet="AGW", min_size=1, max_size=30)          # co-optimal ties everywhere
 genome = st.dictionaries(st.sampled_from([f"p{i}" for i in range(12)]), st.lists(seqs, min_size=1, max_size=3), min_size=1, max_size=8)
-SETTINGS = dict(deadline=None, max_examples=60, suppress_health_check=[HealthCheck.too_slow])
+SETTINGS = dict(deadline=None, max_examples=60, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture], derandomize=True)   # the same examples on every run: a CI gate must not flip on a dice roll (new seeds: --hypothesis-seed=N)
 
 
 @pytest.fixture(scope="module")
