@@ -172,6 +172,10 @@ template <int ROWSTEP, int LDW, int ONLY>
 __device__ __forceinline__ void pc_paralog_probe(const PcDev& d, PcParaRow (&st)[4], const uint64_t (*other)[LDW], int other0, int w0, int wn,
                                                  int (&ex)[4][4], bool rows_are_first_index) {
     const int p_end = (w0 + wn) * 64;
+    // the four opposite rows as arrays of 32-bit halves: a test is one ds_read_b32 + bit extract + multiply-add
+    const uint32_t* half[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) half[j] = (const uint32_t*)&other[other0 + ROWSTEP * j][0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (ONLY >= 0 && i != ONLY) continue;
@@ -180,10 +184,10 @@ __device__ __forceinline__ void pc_paralog_probe(const PcDev& d, PcParaRow (&st)
             if (p >= p_end) break;
             const int e = d.para_ex[st[i].cur];
             ++st[i].cur;
-            const int w = (p >> 6) - w0;
+            const int h = ((p >> 5) - 2 * w0), bit = p & 31;       // which 32-bit half of the staged chunk, which bit of it
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int hit = (int)((other[other0 + ROWSTEP * j][w] >> (p & 63)) & 1ULL);
+                const int hit = (int)((half[j][h] >> bit) & 1u);
                 if (rows_are_first_index) ex[i][j] += e * hit; else ex[j][i] += e * hit;
             }
         }
@@ -203,6 +207,8 @@ __global__ void k_set_lut(double* __restrict__ lut, int sh_dim, int tot_dim, int
 // target genome of shard slot k (an unsharded context owns every genome in order: no table read on the critical path)
 __device__ __forceinline__ int pc_owned(const PcShard& sh, int k) { return sh.ident ? k : sh.owned[k]; }
 
+// (the pocp instance takes 166 registers and runs three waves per SIMD where gcs / jc run four; forcing four with
+// amdgpu_waves_per_eu spills 40 dwords and costs 20 %: N = 20,000 4.02 -> 4.88 ms)
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_distance, double* __restrict__ out, int condensed,
                                                    const double* __restrict__ lut, int sh_dim) {
@@ -247,7 +253,10 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
     uint64_t (*ra)[PWCH + 1] = condensed ? rs : rt;
     uint64_t (*rb)[PWCH + 1] = condensed ? rt : rs;
     // pocp: the paralog lists of my 4 + 4 rows (rows outside the matrix have empty lists)
-    int ex[4][4];
+    // The b side is probed under TRANSPOSED ownership: this thread walks the lists of b-rows fy + 16 i (the wave's lanes share
+    // fy in groups of 16, so a wave sees 4 distinct lists per i, as on the a side -- with its own b-rows fx + 16 i it would see
+    // 16, and the loop runs as long as the longest) against a-rows fx + 16 j, and the sums meet their owners through LDS at the end.
+    int ex[4][4], ex2[4][4];
     PcParaRow st_a[4], st_b[4];
     auto genome_of = [&](bool a_side, int local) {
         if (a_side == (condensed != 0)) return s0 + local < d.N ? s0 + local : -1;                 // an s row
@@ -257,8 +266,8 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ex[i][j] = 0;
-            const int ga = genome_of(true, fy + 16 * i), gb = genome_of(false, fx + 16 * i);
+            for (int j = 0; j < 4; ++j) ex[i][j] = ex2[i][j] = 0;
+            const int ga = genome_of(true, fy + 16 * i), gb = genome_of(false, fy + 16 * i);
             st_a[i].cur = st_a[i].end = st_b[i].cur = st_b[i].end = 0;
             if (ga >= 0) { st_a[i].cur = d.para_off[ga]; st_a[i].end = d.para_off[ga + 1]; }
             if (gb >= 0) { st_b[i].cur = d.para_off[gb]; st_b[i].end = d.para_off[gb + 1]; }
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
         if (w0 + PWCH < d.Wb) fetch(w0 + PWCH);
         if (METRIC == PC_POCP) {
             pc_paralog_probe<16, PWCH + 1, -1>(d, st_a, rb, fx, w0, wn, ex, true);
-            pc_paralog_probe<16, PWCH + 1, -1>(d, st_b, ra, fy, w0, wn, ex, false);
+            pc_paralog_probe<16, PWCH + 1, -1>(d, st_b, ra, fx, w0, wn, ex2, true);        // ex2[i][j]: b-row fy + 16 i, a-row fx + 16 j
         }
         for (int w = 0; w < wn; ++w) {
             uint64_t a[4], b[4];
@@ -292,6 +301,19 @@ __global__ __launch_bounds__(256) void k_set_popc(PcDev d, PcShard sh, int as_di
                     asm("v_bcnt_u32_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %2, %0" : "+v"(acc[i][j]) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)));
                 }
         }
+    }
+    if (METRIC == PC_POCP) {                                         // b-side sums -> the threads that own the pairs (the staging rows are free now)
+        __syncthreads();
+        int* xt = (int*)&rs[0][0];                                   // [64 b-rows][65]  (16,640 of rs's 16,896 bytes)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xt[(fy + 16 * i) * 65 + fx + 16 * j] = ex2[i][j];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ex[i][j] += xt[(fx + 16 * j) * 65 + fy + 16 * i];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
