@@ -705,28 +705,49 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
 
     lap("launch classes");
     // ---- device copies ---------------------------------------------------------------
+    // The tables go through the context's page-locked staging buffer (one memcpy each, then DMA): sent with hipMemcpy straight from
+    // pageable vectors, the larger ones (rem_class 16 B and gene_off 8 B per sequence) left the driver ~20 ms of deferred work
+    // that the FIRST kernel launch after the upload then waited for (tools/wake_experiment.py: fill 622 ms on the host clock
+    // against 599 on the device right after an upload, 599 / 599 after 50 ms of sleep).
+    std::vector<int64_t> rel(g->seq_off, g->seq_off + G + 1);
+    for (auto& x : rel) x -= g->seq_off[0];
+    struct Item { DevBuf* buf; const void* src; size_t bytes; };
+    const Item items[] = {
+        {&c->b_gene_off, gene_off.data(), gene_off.size() * 8}, {&c->b_seq_tmp, rel.data(), rel.size() * 8},
+        {&c->b_gene_q, gene_q.data(), gene_q.size() * 4}, {&c->b_q_gene, q_gene.data(), q_gene.size() * 4},
+        {&c->b_task_rows, task_rows.data(), task_rows.size() * 4}, {&c->b_q_class, q_class.data(), q_class.size()},
+        {&c->b_q_nseg, q_nseg.data(), q_nseg.size()}, {&c->b_rem_class, rem_class.data(), rem_class.size()}};
+    size_t stage_total = 0;
+    for (const Item& it : items) stage_total += (it.bytes + 255) & ~(size_t)255;
+    if (stage_total > c->h_stage_cap) {                       // (part 1's copy out of this buffer has completed)
+        if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+        const size_t want = stage_total + stage_total / 8;
+        hipError_t e = hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault);
+        if (e != hipSuccess) { pc_set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); c->h_stage = nullptr; return PC_ERR_HIP; }
+        c->h_stage_cap = want;
+    }
     const size_t codes_size = (size_t)std::max<int64_t>(code_bytes, 16);
-    {   // raw residues + their offsets -> device, encoded there.  The two staging buffers stay with the context (grow-only):
-        // a hipFree of ~10^8 bytes per upload made the NEXT copy on the context wait 8-25 ms
-        DevBuf& d_raw = c->b_raw; DevBuf& d_seq_off = c->b_seq_tmp;
-        std::vector<int64_t> rel(g->seq_off, g->seq_off + G + 1);
-        for (auto& x : rel) x -= g->seq_off[0];
+    {
+        size_t at = 0;
+        for (const Item& it : items) {
+            if ((rc = abi_rc(it.buf->ensure(std::max<size_t>(it.bytes, 16))))) return rc;
+            if (!it.bytes) continue;
+            memcpy(c->h_stage + at, it.src, it.bytes);
+            PC_HIP(hipMemcpyAsync(it.buf->p, c->h_stage + at, it.bytes, hipMemcpyHostToDevice, c->stream));
+            at += (it.bytes + 255) & ~(size_t)255;
+        }
+        // raw residues (already on their way when staged) -> codes, on the device
         PcLut lut_arg;
         memcpy(lut_arg.v, lut, 256);
-        if ((rc = upload_vec(c->b_gene_off, gene_off)) || (!staged && (rc = upload_raw(d_raw, raw + g->seq_off[0], (size_t)raw_bytes))) || (rc = upload_vec(d_seq_off, rel)) ||
-            (rc = abi_rc(c->b_codes.ensure(codes_size)))) return rc;
+        if ((!staged && (rc = upload_raw(c->b_raw, raw + g->seq_off[0], (size_t)raw_bytes))) || (rc = abi_rc(c->b_codes.ensure(codes_size))) ||
+            (rc = abi_rc(c->b_cls_begin.ensure((ncls_all + 1) * 4)))) return rc;
         if (code_bytes < 16) PC_HIP(hipMemsetAsync(c->b_codes.p, PC_PADCODE, 16, c->stream));
-        rc = pc_launch_encode(d_raw.as<uint8_t>(), d_seq_off.as<int64_t>(), c->b_gene_off.as<int64_t>(), c->dev.gene_len, lut_arg,
+        rc = pc_launch_encode(c->b_raw.as<uint8_t>(), c->b_seq_tmp.as<int64_t>(), c->b_gene_off.as<int64_t>(), c->dev.gene_len, lut_arg,
                               c->b_codes.as<uint8_t>(), G, c->stream);
         hipError_t e = hipStreamSynchronize(c->stream);
         if (rc != PC_OK) return rc;
-        if (e != hipSuccess) { pc_set_error("pc_upload: residue encoding: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+        if (e != hipSuccess) { pc_set_error("pc_upload: residue tables / encoding: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     }
-    if (
-        (rc = upload_vec(c->b_gene_q, gene_q)) || (rc = upload_vec(c->b_q_gene, q_gene)) || (rc = upload_vec(c->b_task_rows, task_rows)) ||
-        (rc = upload_vec(c->b_q_class, q_class)) || (rc = upload_vec(c->b_q_nseg, q_nseg)) || (rc = upload_vec(c->b_rem_class, rem_class)) ||
-        (rc = abi_rc(c->b_cls_begin.ensure((ncls_all + 1) * 4))))
-        return rc;
     c->task_plan.task_rows = c->b_task_rows.as<int32_t>(); c->task_plan.q_class = c->b_q_class.as<uint8_t>();
     c->task_plan.q_nseg = c->b_q_nseg.as<uint8_t>(); c->task_plan.rem_class = c->b_rem_class.as<uint8_t>();
     PcDev& d = c->dev;
