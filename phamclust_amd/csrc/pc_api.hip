@@ -127,6 +127,7 @@ struct pc_ctx {
     std::vector<int32_t> h_gene_len;
     std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
     int max_gene_len = 0, min_gene_len = 0, max_nph = 0, max_ngen = 0;
+    int64_t max_tlen = 0;                    // largest summed translation length of a genome
     // kernel-variant classes over column genes
     int ncls_all = 0;                       // launch classes: variant * 4 + lanes-per-segment bucket, last = general kernel
     std::vector<int32_t> cls_max_lb;        // [ncls_all] longest column sequence that can land in the class (LDS size of its launch)
@@ -484,7 +485,8 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
     c->max_nph = 0;
-    for (int s2 = 0; s2 < N; ++s2) c->max_nph = std::max(c->max_nph, (int)g->nph[s2]);
+    c->max_tlen = 0;
+    for (int s2 = 0; s2 < N; ++s2) { c->max_nph = std::max(c->max_nph, (int)g->nph[s2]); c->max_tlen = std::max(c->max_tlen, (int64_t)g->tlen[s2]); }
     c->n_residue_bytes_in = g->seq_off[G] - g->seq_off[0];
     rc = apply_shard(c, 0, 1);
     if (rc != PC_OK) return rc;
@@ -1233,8 +1235,31 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     as_distance = as_distance ? 1 : 0;
     PC_HIP(hipEventRecord(c->ev[0], st));
 
-    static const char* set_force = getenv("PC_SET_KERNEL");          // A/B knob: walker | sparse force the older pocp / af kernels
-    if (metric == PC_GCS || metric == PC_JC || (metric == PC_POCP && !set_force)) {
+    // Which kernel fills a set metric (measured crossovers, `profiles/r03_p_sparse64_record.txt`; PC_SET_KERNEL =
+    // popc | sparse | sparse64 | walker forces one for A/B runs and for the tests that keep every one of them honest):
+    //   gcs, jc          popcount tiles
+    //   pocp             popcount tiles + paralog excess, from ~6,000 genomes the 64 x 64 sparse tile kernel
+    //   af               the 32 x 32 sparse tile kernel below ~2,200 genomes, the 64 x 64 one above
+    // The 64 x 64 kernel takes "sum == 0" for "no shared pham" and sums in 32 bits: it needs every entry value >= 1 (a
+    // genome with an empty translation fails that for af) and genome totals below 2^32; else af falls back to the
+    // 32 x 32 kernel / the shared-pham walker (crossover ~3,500 genomes), pocp to the popcount tiles.
+    enum { K_POPC, K_SPARSE32, K_SPARSE64, K_WALKER };
+    int kernel = K_POPC;
+    if (metric == PC_POCP || metric == PC_AF) {
+        const char* set_force = getenv("PC_SET_KERNEL");                   // (read per fill: the tests switch it between launches)
+        const int64_t area = (int64_t)d.N * c->shard.nown;
+        const bool s64_ok = metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
+        if (metric == PC_POCP) kernel = (s64_ok && area > (int64_t)6000 * 6000) ? K_SPARSE64 : K_POPC;
+        else if (s64_ok) kernel = area >= (int64_t)2200 * 2200 ? K_SPARSE64 : K_SPARSE32;
+        else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
+        if (set_force) {
+            if (!strcmp(set_force, "popc") && metric == PC_POCP) kernel = K_POPC;
+            else if (!strcmp(set_force, "sparse")) kernel = K_SPARSE32;
+            else if (!strcmp(set_force, "sparse64") && s64_ok) kernel = K_SPARSE64;
+            else if (!strcmp(set_force, "walker")) kernel = K_WALKER;
+        }
+    }
+    if (metric == PC_GCS || metric == PC_JC || (metric == PC_POCP && kernel == K_POPC)) {
         // epilogue table: gcs / jc over (shared, nph_s + nph_t), at most (max_nph+1) x (2 max_nph+1) doubles; pocp over
         // (conserved, ngen_s + ngen_t), (2 max_ngen+1)^2; skipped when huge.  It depends on (metric, as_distance, that maximum)
         // only, so it is rebuilt only when one of them changes.
@@ -1253,15 +1278,13 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         PC_HIP(hipEventRecord(c->ev[3], st));
         local.n_chunks = 1;
     } else if (metric == PC_POCP || metric == PC_AF) {
-        // small matrices: the sparse tile kernel; large ones: the shared-pham walker (crossover measured at ~3,500 genomes;
-        // PC_SET_KERNEL=walker|sparse forces one for A/B runs)
-        const char* force = set_force;
-        const bool walker = force ? !strcmp(force, "walker") : (int64_t)d.N * c->shard.nown > (int64_t)3500 * 3500;
-        if (walker) {
+        const int mode = metric == PC_POCP ? PCW_POCP : PCW_AF;
+        if (kernel == K_WALKER) {
             PcWalkArgs a; memset(&a, 0, sizeof(a));
             a.out = out; a.as_distance = as_distance; a.condensed = condensed;
-            rc = pc_launch_walk(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, a, st);
-        } else rc = pc_launch_sparse(metric == PC_POCP ? PCW_POCP : PCW_AF, d, c->shard, out, as_distance, condensed, st);
+            rc = pc_launch_walk(mode, d, c->shard, a, st);
+        } else if (kernel == K_SPARSE64) rc = pc_launch_sparse64(mode, d, c->shard, out, as_distance, condensed, st);
+        else rc = pc_launch_sparse(mode, d, c->shard, out, as_distance, condensed, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
         local.n_chunks = 1;

@@ -94,6 +94,7 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
                        double* lut, bool build_lut, int sh_dim, int tot_dim, hipStream_t st);
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
 int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st);   // pocp / af
+int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st); // pocp / af, large matrices
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);
 // residue bytes -> codes on the device (pc_plan.hip): gene k's raw bytes [seq_off[k], seq_off[k+1]) go through the LUT to

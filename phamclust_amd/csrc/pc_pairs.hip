@@ -14,6 +14,7 @@
 // lanes of distinct rows is conflict-free); each workgroup owns a 32x32 tile of pairs.
 // These kernels are HBM/LDS-bound integer work: no MFMA.
 #include "pc_common.h"
+#include <type_traits>
 #include "../../include/phamclust_hip.h"
 
 #define TS 32          // tile edge (genomes)
@@ -103,9 +104,8 @@ __host__ __device__ __forceinline__ unsigned pc_super_edge(unsigned ntx, unsigne
 // XCD x takes, in super-tile row sy, the columns sx = 8c + ((x - sy) mod 8): every XCD gets every eighth super-tile of
 // each row AND of each column, so the triangular (or, for a shard, trapezoid) region of live tiles is dealt evenly --
 // dealing whole columns to XCDs left them 40 % apart on the triangle.
-__device__ __forceinline__ bool pc_tile_of_block(int ntx, int nty, int& tx, int& ty) {
+__device__ __forceinline__ bool pc_tile_of_index(unsigned n, int ntx, int nty, int& tx, int& ty) {
     const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty);
-    const unsigned n = blockIdx.x;
     const unsigned xcd = n & 7u, k = n >> 3;
     const unsigned stx = ((unsigned)ntx + e - 1) / e, stx8 = (stx + 7u) / 8u;
     const unsigned m = k / (e * e), within = k % (e * e);
@@ -115,6 +115,7 @@ __device__ __forceinline__ bool pc_tile_of_block(int ntx, int nty, int& tx, int&
     ty = (int)(sy * e + within / e);
     return tx < ntx && ty < nty;
 }
+__device__ __forceinline__ bool pc_tile_of_block(int ntx, int nty, int& tx, int& ty) { return pc_tile_of_index(blockIdx.x, ntx, nty, tx, ty); }
 static unsigned pc_tile_grid(int ntx, int nty) {
     const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty);
     const unsigned stx = ((unsigned)ntx + e - 1) / e, sty = ((unsigned)nty + e - 1) / e;
@@ -628,6 +629,181 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
     else hipLaunchKernelGGL(k_sparse_tile<PCW_AF>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_tile launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// K2 for LARGE matrices (r03): the sparse formulation again, on 64 x 64 tiles with row-per-wave probes.
+//
+// What kept the 32 x 32 kernel behind the walker at N = 20,000 (profiles/r03_c_sparse_tile_experiment.txt): a tile pays for
+// 4 x 32 entry lists (build + probe, both directions) whatever its 1,024 pairs share, and its per-bit add loops diverge --
+// most probes of a source row hit no target or one, a few (phams of the target cluster's pool) hit twenty, and a wave
+// runs the longest loop of its 64 lanes.  Here
+//   * a tile is 64 x 64 pairs (masks are two u32 per pham): the list work per pair halves;
+//   * eight waves; a wave owns eight rows of either side and loads ALL their entries (128 per row) into registers with
+//     one round of coalesced loads at the start of the tile -- one memory latency per tile, not one per phase (a first
+//     version that fetched row after row spent 3.0 of its 7.5 ms waiting for them);
+//   * masks are built and probed from those registers; a wave probes ONE row at a time, 64 of its entries per step;
+//   * a probe that hits at most two rows of the other side adds them itself (LDS atomics, two short iterations);
+//   * a probe that hits more is BROADCAST (readlane): its 64-bit mask becomes the EXEC mask of one v_add into a register
+//     the 64 lanes hold for the 64 rows of the other side -- no divergence, no LDS traffic; the register is flushed into
+//     the LDS accumulators once per probing row.
+// Accumulators: u32 in LDS, row stride 65 (both directions conflict free).  "No shared pham" is "sum == 0": the host uses
+// this kernel only when every entry value is >= 1 (always true for gene counts; for summed lengths unless a translation
+// is empty) and every genome's total stays below 2^32 -- otherwise the walker runs.
+// ---------------------------------------------------------------------------------
+#define S6_T 64
+#define S6_LD 65
+#define S6_WAVES 8
+#define S6_RPW (S6_T / S6_WAVES)                                  // rows (of either side) a wave owns
+#define S6_B 2                                                    // 64-entry batches of a row held in registers
+template <int MODE>
+__global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+    uint32_t* colmask = sp_lds;                                                    // [CH][2]
+    uint32_t* acc = sp_lds + 2 * CH;                                               // [64 sources][65]
+    __shared__ int g_s[S6_T], g_t[S6_T];                                           // genome of tile row r, -1: none
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int32_t* __restrict__ val = MODE == PCW_POCP ? d.ent_cnt : d.ent_len;
+    // Unit n of the XCD-aware tile order goes to workgroup n mod gridDim (a multiple of 8, so a workgroup keeps to the tiles of
+    // its XCD).  Tiles differ in cost by 10 x (a tile inside a cluster of related genomes shares ~85 phams per pair, one between
+    // clusters ~3), so the deal must stay fine: measured at N = 20,000 with gridDim = m x the 512 resident workgroups, m = 1: 4.40 ms,
+    // 8: 3.73, 64: 3.37 (a workgroup then takes ~3 units, half of them below the diagonal), one workgroup per unit: 3.51;
+    // N = 8,000: best at m = 16, again ~3 units each.  Hence gridDim = units / 3.
+#pragma unroll 1
+    for (unsigned unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    int tile_x, tile_y;
+    if (!pc_tile_of_index(unit, (d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, tile_x, tile_y)) continue;
+    const int s0 = tile_x * S6_T, k0 = tile_y * S6_T;
+    const int klast = min(k0 + S6_T, sh.nown) - 1;
+    if (s0 >= pc_owned(sh, klast)) continue;
+    // lane l looks at row l of either side: genome, then (per chunk) where its entries start and end
+    const int gs_l = s0 + lane < d.N ? s0 + lane : -1, gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;
+    if (wave == 0) { g_s[lane] = gs_l; g_t[lane] = gt_l; }
+    for (int i = tid; i < S6_T * S6_LD; i += 64 * S6_WAVES) acc[i] = 0u;
+    for (int p0 = 0; p0 < d.Wb * 64; p0 += CH) {
+        const int w0 = p0 >> 6, w1 = min(d.Wb, (p0 + CH) >> 6);
+        // my rows' entries of this chunk, sources and targets: ranges (wave-uniform), then 2 x 64 entries per row in registers
+        uint32_t rl_s = 0, rh_s = 0, rl_t = 0, rh_t = 0;
+        if (gs_l >= 0) { rl_s = d.rankpre[(int64_t)gs_l * d.Wb + w0]; rh_s = w1 < d.Wb ? d.rankpre[(int64_t)gs_l * d.Wb + w1] : d.ent_off[gs_l + 1]; }
+        if (gt_l >= 0) { rl_t = d.rankpre[(int64_t)gt_l * d.Wb + w0]; rh_t = w1 < d.Wb ? d.rankpre[(int64_t)gt_l * d.Wb + w1] : d.ent_off[gt_l + 1]; }
+        uint32_t lo_s[S6_RPW], hi_s[S6_RPW], lo_t[S6_RPW], hi_t[S6_RPW];
+#pragma unroll
+        for (int rr = 0; rr < S6_RPW; ++rr) {
+            const int r = wave + S6_WAVES * rr;
+            lo_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_s, r); hi_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_s, r);
+            lo_t[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_t, r); hi_t[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_t, r);
+        }
+        int ph_s[S6_RPW][S6_B], ph_t[S6_RPW][S6_B]; uint32_t v_s[S6_RPW][S6_B], v_t[S6_RPW][S6_B];
+#pragma unroll
+        for (int rr = 0; rr < S6_RPW; ++rr)
+#pragma unroll
+            for (int b = 0; b < S6_B; ++b) {
+                const uint32_t es = lo_s[rr] + (uint32_t)(64 * b + lane), et = lo_t[rr] + (uint32_t)(64 * b + lane);
+                const bool is = es < hi_s[rr], it = et < hi_t[rr];
+                ph_s[rr][b] = is ? d.ent_pham[es] - p0 : -1; v_s[rr][b] = is ? (uint32_t)val[es] : 0u;
+                ph_t[rr][b] = it ? d.ent_pham[et] - p0 : -1; v_t[rr][b] = it ? (uint32_t)val[et] : 0u;
+            }
+        // one direction: the rows of one side build the masks, the rows of the other probe them.  TO_ROW: the probing rows are
+        // the accumulator rows (sources probe), else its columns (targets probe)
+        auto hit = [&](auto to_row, int r, int ph, uint32_t v, uint32_t& hs) {
+            uint2 m = make_uint2(0u, 0u);
+            if (ph >= 0) m = *(const uint2*)&colmask[2 * ph];
+            const int pc = __popc(m.x) + __popc(m.y);
+            if (pc > 0 && pc <= 2) {                                                // one or two hits: this lane adds them
+                const unsigned long long mm = ((unsigned long long)m.y << 32) | m.x;
+                const int o1 = __builtin_ctzll(mm), o2 = 63 - __builtin_clzll(mm);
+                atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + o1 : o1 * S6_LD + r], v);
+                if (pc == 2) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + o2 : o2 * S6_LD + r], v);
+            }
+            unsigned long long heavy = __ballot(pc > 2);                            // many hits: the wave adds them, lanes = rows of the other side
+            while (heavy) {
+                const int k = __builtin_ctzll(heavy);
+                asm("s_bitset0_b64 %0, %1" : "+s"(heavy) : "s"(k));
+                const unsigned long long mk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m.y, k) << 32) |
+                                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m.x, k);
+                const uint32_t vk = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
+                // (every lane of the workgroup is active here -- 512 threads, wave-uniform control flow -- so EXEC is all ones before and after)
+                asm volatile("s_mov_b64 exec, %1\n\tv_add_u32 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(hs) : "s"(mk), "s"(vk));
+            }
+        };
+        auto direction = [&](auto to_row, const int (&bph)[S6_RPW][S6_B], const uint32_t (&blo)[S6_RPW], const uint32_t (&bhi)[S6_RPW],
+                             const int (&qph)[S6_RPW][S6_B], const uint32_t (&qv)[S6_RPW][S6_B], const uint32_t (&qlo)[S6_RPW], const uint32_t (&qhi)[S6_RPW]) {
+            for (int i = tid * 4; i < 2 * CH; i += 256 * S6_WAVES) *(uint4*)&colmask[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < S6_RPW; ++rr) {
+                const int r = wave + S6_WAVES * rr;
+                const uint32_t bit = 1u << (r & 31); const int half = r >> 5;
+#pragma unroll
+                for (int b = 0; b < S6_B; ++b) if (bph[rr][b] >= 0) atomicOr(&colmask[2 * bph[rr][b] + half], bit);
+                for (uint32_t e0 = blo[rr] + 64u * S6_B; e0 < bhi[rr]; e0 += 64u) {          // rows with more entries than the registers hold
+                    const uint32_t e = e0 + (uint32_t)lane;
+                    if (e < bhi[rr]) atomicOr(&colmask[2 * (d.ent_pham[e] - p0) + half], bit);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < S6_RPW; ++rr) {
+                const int r = wave + S6_WAVES * rr;
+                uint32_t hs = 0;
+#pragma unroll
+                for (int b = 0; b < S6_B; ++b) hit(to_row, r, qph[rr][b], qv[rr][b], hs);
+                for (uint32_t e0 = qlo[rr] + 64u * S6_B; e0 < qhi[rr]; e0 += 64u) {
+                    const uint32_t e = e0 + (uint32_t)lane;
+                    const bool in = e < qhi[rr];
+                    hit(to_row, r, in ? d.ent_pham[e] - p0 : -1, in ? (uint32_t)val[e] : 0u, hs);
+                }
+                if (hs) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + lane : lane * S6_LD + r], hs);
+            }
+            __syncthreads();                                                        // probes done before the masks are cleared again
+        };
+        direction(std::true_type{}, ph_t, lo_t, hi_t, ph_s, v_s, lo_s, hi_s);       // masks over the targets, the sources' entries probe
+        direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);      // the other way round
+    }
+    // finish: 4,096 pairs, 8 per thread; consecutive lanes run along the output's contiguous direction
+#pragma unroll 4
+    for (int q = 0; q < S6_T * S6_T / (64 * S6_WAVES); ++q) {
+        const int idx = tid + 64 * S6_WAVES * q;
+        const int fast = idx & 63, slow = idx >> 6;
+        const int ls = condensed ? slow : fast, lt = condensed ? fast : slow;
+        const int s = g_s[ls], t = g_t[lt];
+        if (s < 0 || t < 0 || s >= t) continue;
+        const uint32_t cons = acc[ls * S6_LD + lt];
+        double sim = 0.0;
+        if (cons) {
+            if (MODE == PCW_POCP) sim = (double)cons / (double)(d.ngen[s] + d.ngen[t]);    // metrics.py:104-110
+            else sim = (double)cons / (double)(d.tlen[s] + d.tlen[t]);                      // metrics.py:149-152
+        }
+        out[pc_out_index(d, sh, s, t, k0 + lt, condensed)] = pc_finish(sim, as_distance);
+    }
+    __syncthreads();                                                                // the next tile clears acc and rewrites g_s, g_t
+    }
+}
+
+int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
+    if (sh.nown <= 0 || d.N <= 1) return PC_OK;
+    // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators), else 4,096 at a time
+    const int P64 = d.Wb * 64;
+    const int CH = P64 <= 7680 ? P64 : 4096;
+    const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
+    const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T);
+    static const unsigned resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(2 * cus + 7) / 8u * 8u; }();
+    // three units per workgroup (see the kernel), never fewer workgroups than fit the chip at once
+    const unsigned want = std::max(resident, ((n_units + 2u) / 3u + 7u) / 8u * 8u);
+    dim3 grid(std::min(n_units, want)), block(64 * S6_WAVES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_sparse_tile64<PCW_POCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_sparse_tile64<PCW_AF>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+            pc_set_error("k_sparse_tile64: cannot raise the dynamic LDS limit"); return PC_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile64<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
+    else hipLaunchKernelGGL(k_sparse_tile64<PCW_AF>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_sparse_tile64 launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
 }
 

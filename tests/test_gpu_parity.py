@@ -306,6 +306,17 @@ def test_round6_matches_python(gpu_ctx):
     assert np.array_equal(got, want)
 
 
+def test_round6_every_millionth(gpu_ctx):
+    """round(x, 6) of every k / 1e6, k in [0, 2 * 10^6] (it rounds to itself), and of x just off each of them, against CPython."""
+    k = np.arange(0, 2_000_001, dtype=np.float64)
+    xs = k / 1e6
+    assert np.array_equal(gpu_ctx.round6(xs), xs)                        # x = k / 1e6 rounds to itself
+    rng = np.random.default_rng(21)
+    near = xs[:1_000_001] + rng.uniform(-4e-7, 4e-7, 1_000_001)
+    near = near[(near >= 0.0) & (near <= 1.0)][::7]
+    assert np.array_equal(gpu_ctx.round6(near), np.array([round(float(x), 6) for x in near]))
+
+
 def test_edge_cases(gpu_ctx, native_built):
     from phamclust_amd.genome import Genome
     from phamclust_amd.pack import pack_genomes
@@ -1155,6 +1166,72 @@ def test_borrowed_result_loan(gpu_ctx, native_built):
     gpu_ctx.upload(packed)
     with pytest.raises(hip.HipLibraryError):
         again.copy()
+
+
+def _set_kernel_case(rng, n_genomes, n_phams, wide_rows=(), shared_by_all=(), empty_translation_in=None):
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    genomes = []
+    for k in range(n_genomes):
+        g = Genome(f"g{k:04d}")
+        n = 420 if k in wide_rows else int(rng.integers(0 if k % 17 == 0 else 20, 110))
+        phams = set(int(x) for x in rng.choice(n_phams, size=n, replace=False)) | set(shared_by_all)
+        if k == 34:
+            phams = set()                                                # a genome without genes
+        elif k % 5 == 0:
+            phams |= set(range(100 * (k % 3), 100 * (k % 3) + 60))       # blocks of genomes sharing dozens of phams: masks with many bits
+        for p in sorted(phams):
+            for _ in range(int(rng.integers(1, 4)) if p % 11 == 0 else 1):
+                g.add(f"p{p:05d}", "M" * int(rng.integers(1, 40)))
+        if k == empty_translation_in:
+            g.add("p00003", "")
+        genomes.append(g)
+    return pack_genomes(genomes)
+
+
+def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
+    """pocp / af have four kernels behind one selector (popcount tiles + paralog excess, the 32 x 32 and 64 x 64 sparse tile
+    kernels, the shared-pham walker; pc_api.hip picks by size).  Each one, forced through PC_SET_KERNEL, must give the oracle's
+    matrix (metrics.py:83-157) on a data set that reaches their corners: more phams than one mask chunk holds (64 x 64: three
+    chunks), rows with more entries than a wave keeps in registers, phams shared by every genome and by blocks of genomes
+    (broadcast adds), genomes without genes, similarity and distance, unsharded and as a shard."""
+    import torch
+    O = _oracle()
+    rng = np.random.default_rng(11)
+    packed = _set_kernel_case(rng, 150, 40000, wide_rows=(3, 77, 149), shared_by_all=(5, 4100, 39999))
+    assert packed.words_per_row * 64 > 7680                                  # more than one mask chunk of the 64 x 64 kernel
+    want = {(m, dist): O.fill(packed, m, dist) for m in ("pocp", "af") for dist in (True, False)}
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for kernel in ("popc", "sparse", "sparse64", "walker"):
+            os.environ["PC_SET_KERNEL"] = kernel                             # read per fill
+            gpu_ctx.upload(packed, residues=False)
+            for (m, dist), w in want.items():
+                assert np.array_equal(gpu_ctx.fill(m, dist), w), (kernel, m, dist)
+            gpu_ctx.set_shard(1, 3)
+            t_rank, t_lbase = gpu_ctx.shard_table()
+            n = packed.n_genomes
+            for m in ("pocp", "af"):
+                buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
+                gpu_ctx.fill_shard_dev(m, True, buf.data_ptr(), stream)
+                torch.cuda.synchronize()
+                got = buf.cpu().numpy()
+                w = want[(m, True)]
+                for t in range(1, n):
+                    if t_rank[t] != 1:
+                        continue
+                    col = np.array([w[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
+                    assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), (kernel, m, t)
+            gpu_ctx.set_shard(0, 1)
+        # an empty translation makes "sum == 0" ambiguous: the 64 x 64 kernel must step aside, whatever was asked for
+        os.environ["PC_SET_KERNEL"] = "sparse64"
+        odd = _set_kernel_case(rng, 40, 300, empty_translation_in=2)
+        gpu_ctx.upload(odd, residues=False)
+        for m in ("pocp", "af"):
+            assert np.array_equal(gpu_ctx.fill(m), O.fill(odd, m)), m
+    finally:
+        os.environ.pop("PC_SET_KERNEL", None)
+        gpu_ctx.set_shard(0, 1)
 
 
 def test_pocp_paralog_lists_spill_and_wide_entries(gpu_ctx, native_built):

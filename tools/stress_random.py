@@ -5,7 +5,7 @@ row of the tie-rule table (kernel and oracle switched together): `python tools/s
 r01: seed 4242, 1,500 collections, 9,000 fills, 0 mismatches; seed 20261004, 4,000 collections, 24,000 fills, 0 mismatches.
 r02 (64-bit lexicographic-max cell, all 8 rules): see profiles/r02_stress.txt.
 r03: every collection additionally draws a plan budget (aai / peq fills in one piece or in many chunks), a two-part or a full
-upload, both popcount tile kernels (PC_POPC_TILE, read per launch) and, every fourth one, a shard of a 2- or 3-rank deal compared with
+upload, both popcount tile kernels (PC_POPC_TILE, read per launch), every pocp / af kernel (PC_SET_KERNEL) and, every fourth one, a shard of a 2- or 3-rank deal compared with
 the same pairs of the unsharded matrix: see profiles/r03_stress.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,6 +41,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
     ctx.upload(packed, residues=bool(rng.random() < 0.5))              # two-part upload: the residues follow on demand
     ctx.set_plan_budget(int(rng.choice([0, 56, 56 * 7, 56 * 60, 56 * 2000])))   # 0: automatic; tiny: one target genome per chunk
     os.environ["PC_POPC_TILE"] = str(rng.choice(["32", "64"]))
+    os.environ["PC_SET_KERNEL"] = str(rng.choice(["popc", "sparse", "sparse64", "walker"]))   # pocp / af kernel, read per fill
     for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
         got = ctx.fill(metric, as_distance=bool(trial & 1))
         want = O.fill(packed, metric, as_distance=bool(trial & 1))
