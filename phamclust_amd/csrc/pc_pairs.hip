@@ -792,14 +792,7 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     // three units per workgroup (see the kernel), never fewer workgroups than fit the chip at once
     const unsigned want = std::max(resident, ((n_units + 2u) / 3u + 7u) / 8u * 8u);
     dim3 grid(std::min(n_units, want)), block(64 * S6_WAVES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_sparse_tile64<PCW_POCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_sparse_tile64<PCW_AF>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
-            pc_set_error("k_sparse_tile64: cannot raise the dynamic LDS limit"); return PC_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    // (up to 78 KB of dynamic LDS: HIP on this hardware needs no opt-in above 64 KB -- the K4 launches take up to 160 KB the same way)
     if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile64<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
     else hipLaunchKernelGGL(k_sparse_tile64<PCW_AF>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
     hipError_t e = hipGetLastError();

@@ -1223,8 +1223,14 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
                     col = np.array([w[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
                     assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), (kernel, m, t)
             gpu_ctx.set_shard(0, 1)
-        # an empty translation makes "sum == 0" ambiguous: the 64 x 64 kernel must step aside, whatever was asked for
+        # one mask chunk of more than 64 KB of LDS (5,952 < phams <= 7,680)
         os.environ["PC_SET_KERNEL"] = "sparse64"
+        mid = _set_kernel_case(rng, 120, 25000, wide_rows=(9,))
+        assert 5952 < mid.words_per_row * 64 <= 7680
+        gpu_ctx.upload(mid, residues=False)
+        for m in ("pocp", "af"):
+            assert np.array_equal(gpu_ctx.fill(m), O.fill(mid, m)), m
+        # an empty translation makes "sum == 0" ambiguous: the 64 x 64 kernel must step aside, whatever was asked for
         odd = _set_kernel_case(rng, 40, 300, empty_translation_in=2)
         gpu_ctx.upload(odd, residues=False)
         for m in ("pocp", "af"):
