@@ -94,18 +94,20 @@ __device__ __forceinline__ int64_t pc_out_index(const PcDev& d, const PcShard& s
 // super-tiles of up to 8 x 8 tiles and consecutive workgroups of one XCD walk one super-tile, so the ~100 workgroups
 // resident on an XCD share the rows of one or two super-tiles (0.29 GB and 1.3 GB after the change).  Affinity only:
 // nothing depends on where a workgroup really runs.
-// Super-tile edge: 8 tiles, halved while that would leave an XCD with fewer than 16 super-tiles (small matrices must
+// Super-tile edge: 8 tiles (16 for k_sparse_tile64, whose tiles re-read 800 B of entry lists per row: 0.84 -> 0.56 GB fetched at
+// N = 20,000; for the popcount tiles and the walker 16 changed nothing measurable), halved while that would leave an XCD with
+// fewer than 16 super-tiles (small matrices must
 // still spread over all 8 XCDs; at edge 1 the deal is tile by tile).
-__host__ __device__ __forceinline__ unsigned pc_super_edge(unsigned ntx, unsigned nty) {
-    unsigned e = 8;
+__host__ __device__ __forceinline__ unsigned pc_super_edge(unsigned ntx, unsigned nty, unsigned top = 8) {
+    unsigned e = top;
     while (e > 1 && ((ntx + e - 1) / e) * ((nty + e - 1) / e) < 128u) e >>= 1;
     return e;
 }
 // XCD x takes, in super-tile row sy, the columns sx = 8c + ((x - sy) mod 8): every XCD gets every eighth super-tile of
 // each row AND of each column, so the triangular (or, for a shard, trapezoid) region of live tiles is dealt evenly --
 // dealing whole columns to XCDs left them 40 % apart on the triangle.
-__device__ __forceinline__ bool pc_tile_of_index(unsigned n, int ntx, int nty, int& tx, int& ty) {
-    const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty);
+__device__ __forceinline__ bool pc_tile_of_index(unsigned n, int ntx, int nty, int& tx, int& ty, unsigned top = 8) {
+    const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty, top);
     const unsigned xcd = n & 7u, k = n >> 3;
     const unsigned stx = ((unsigned)ntx + e - 1) / e, stx8 = (stx + 7u) / 8u;
     const unsigned m = k / (e * e), within = k % (e * e);
@@ -115,9 +117,9 @@ __device__ __forceinline__ bool pc_tile_of_index(unsigned n, int ntx, int nty, i
     ty = (int)(sy * e + within / e);
     return tx < ntx && ty < nty;
 }
-__device__ __forceinline__ bool pc_tile_of_block(int ntx, int nty, int& tx, int& ty) { return pc_tile_of_index(blockIdx.x, ntx, nty, tx, ty); }
-static unsigned pc_tile_grid(int ntx, int nty) {
-    const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty);
+__device__ __forceinline__ bool pc_tile_of_block(int ntx, int nty, int& tx, int& ty, unsigned top = 8) { return pc_tile_of_index(blockIdx.x, ntx, nty, tx, ty, top); }
+static unsigned pc_tile_grid(int ntx, int nty, unsigned top = 8) {
+    const unsigned e = pc_super_edge((unsigned)ntx, (unsigned)nty, top);
     const unsigned stx = ((unsigned)ntx + e - 1) / e, sty = ((unsigned)nty + e - 1) / e;
     return sty * ((stx + 7u) / 8u) * 8u * e * e;
 }
@@ -657,6 +659,7 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 #define S6_WAVES 8
 #define S6_RPW (S6_T / S6_WAVES)                                  // rows (of either side) a wave owns
 #define S6_B 2                                                    // 64-entry batches of a row held in registers
+#define S6_SUPER 16                                               // super-tile edge in tiles: 2 x 1,024 rows' entry lists = 1.6 MB of an XCD's 4-MB L2
 template <int MODE>
 __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
 #pragma unroll 1
     for (unsigned unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     int tile_x, tile_y;
-    if (!pc_tile_of_index(unit, (d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, tile_x, tile_y)) continue;
+    if (!pc_tile_of_index(unit, (d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, tile_x, tile_y, S6_SUPER)) continue;
     const int s0 = tile_x * S6_T, k0 = tile_y * S6_T;
     const int klast = min(k0 + S6_T, sh.nown) - 1;
     if (s0 >= pc_owned(sh, klast)) continue;
@@ -787,7 +790,7 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     const int P64 = d.Wb * 64;
     const int CH = P64 <= 7680 ? P64 : 4096;
     const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
-    const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T);
+    const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
     static const unsigned resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(2 * cus + 7) / 8u * 8u; }();
     // three units per workgroup (see the kernel), never fewer workgroups than fit the chip at once
     const unsigned want = std::max(resident, ((n_units + 2u) / 3u + 7u) / 8u * 8u);
