@@ -628,6 +628,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
         // (pc_nw.hip, PC_INC16_MAX_W), which is exact only while the column holds none of those (as a row, it is fine)
         u_cls[u] = godd[u_gene[u]] ? pc_class_of(len, len_var[len], true) : len_cls[len]; ++cls_count[u_cls[u]];
     }
+    lap("  classes per sequence");
     if (ncls_all > 250) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // class ids travel in a byte, 255 = none
     c->ncls_all = ncls_all;
     std::vector<int64_t> cls_pos(ncls_all, 0);
@@ -659,6 +660,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
             const uint8_t cr = len_rem[(size_t)len * 16 + r];
             if (cr != 255) c->cls_max_lb[cr] = std::max(c->cls_max_lb[cr], len);
         }
+    lap("  remainder chooser");
     // ranks inside a class follow sequence length (then first occurrence): the plan's sort then hands every bucket its
     // rows in length order, so the row streams of a task, dealt round-robin, stay in step and start their alignments
     // in the same steps (the per-step cost of an alignment start is paid once per wave, not once per segment; measured
@@ -671,6 +673,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
         for (int u = 0; u < U; ++u) u_order[at[gene_len[u_gene[u]]]++] = u;
     }
     for (int u : u_order) q_of_u[u] = (uint32_t)cls_pos[u_cls[u]]++;        // (serial: a rank is its predecessors' count)
+    lap("  ranks");
     {   // "any byte" classes a remainder may be sent to: their longest column gene (serial, rare)
         for (int u = 0; u < U; ++u) {
             const int len = gene_len[u_gene[u]];
