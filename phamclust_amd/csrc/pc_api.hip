@@ -463,13 +463,22 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         para_off[N] = (uint32_t)at;
         c->max_ngen = max_ngen;
     }
-    const size_t total_bytes2 = o_para + 2 * para_stride;
+    // (pham, summed length) and (pham, gene count) side by side -- the 64 x 64 sparse tile kernel takes an entry with one 8-byte
+    // load -- are made on the device from the three arrays above (k_pair_entries): nothing more to stage or to send
+    const size_t total_staged = o_para + 2 * para_stride;
+    const size_t o_pair_len = (total_staged + 255) & ~(size_t)255, o_pair_cnt = o_pair_len + 2 * ent_stride;
+    const size_t total_bytes2 = o_pair_cnt + 2 * ent_stride;
     lap("entries, rank table");
     if ((rc = abi_rc(c->b_sets.ensure(total_bytes2)))) return rc;
     // (an idle GPU answers its first command after 10-25 ms, whatever the command -- DMA copy, blocking copy or a copy
     // kernel all showed it when uploads followed each other with nothing in between, `tools/upload_timing.py`; that is the
     // device waking up, not this copy: behind a fill the same copy takes 0.3 ms)
-    PC_HIP(hipMemcpyAsync(c->b_sets.p, hs, total_bytes2, hipMemcpyHostToDevice, c->stream));
+    PC_HIP(hipMemcpyAsync(c->b_sets.p, hs, total_staged, hipMemcpyHostToDevice, c->stream));
+    {
+        uint8_t* dsb = (uint8_t*)c->b_sets.p;
+        if ((rc = pc_launch_pair_entries((const int32_t*)(dsb + o_ent + 3 * ent_stride), (const int32_t*)(dsb + o_ent + ent_stride), (const int32_t*)(dsb + o_ent),
+                                         (uint2*)(dsb + o_pair_len), (uint2*)(dsb + o_pair_cnt), (int64_t)E, c->stream))) return rc;
+    }
     PC_HIP(hipStreamSynchronize(c->stream));
     lap("h2d sets");
     uint8_t* ds = (uint8_t*)c->b_sets.p;
@@ -482,6 +491,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     d.gene_len = (const int32_t*)(ds + o_gene_len); d.ent_off = (const uint32_t*)(ds + o_ent_off);
     d.nph = (const int32_t*)(ds + o_nph); d.ngen = (const int32_t*)(ds + o_ngen); d.tlen = (const int64_t*)(ds + o_tlen);
     d.para_off = (const uint32_t*)(ds + o_para_off); d.para_pham = (const int32_t*)(ds + o_para); d.para_ex = (const int32_t*)(ds + o_para + para_stride);
+    d.ent_pair_len = (const uint2*)(ds + o_pair_len); d.ent_pair_cnt = (const uint2*)(ds + o_pair_cnt);
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
     c->max_nph = 0;
@@ -1242,7 +1252,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     // popc | sparse | sparse64 | walker forces one for A/B runs and for the tests that keep every one of them honest):
     //   gcs, jc          popcount tiles
     //   pocp             popcount tiles + paralog excess, from ~6,000 genomes the 64 x 64 sparse tile kernel
-    //   af               the 32 x 32 sparse tile kernel below ~2,200 genomes, the 64 x 64 one above
+    //   af               the 32 x 32 sparse tile kernel below ~1,900 genomes, the 64 x 64 one above
     // The 64 x 64 kernel takes "sum == 0" for "no shared pham" and sums in 32 bits: it needs every entry value >= 1 (a
     // genome with an empty translation fails that for af) and genome totals below 2^32; else af falls back to the
     // 32 x 32 kernel / the shared-pham walker (crossover ~3,500 genomes), pocp to the popcount tiles.
@@ -1253,7 +1263,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         const int64_t area = (int64_t)d.N * c->shard.nown;
         const bool s64_ok = metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
         if (metric == PC_POCP) kernel = (s64_ok && area > (int64_t)6000 * 6000) ? K_SPARSE64 : K_POPC;
-        else if (s64_ok) kernel = area >= (int64_t)2200 * 2200 ? K_SPARSE64 : K_SPARSE32;
+        else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
         if (set_force) {
             if (!strcmp(set_force, "popc") && metric == PC_POCP) kernel = K_POPC;

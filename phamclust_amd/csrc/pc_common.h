@@ -23,6 +23,8 @@ struct PcDev {
     const uint32_t* rankpre;          // [N][Wb]   entry index of the first set bit of word w of genome g
     const int32_t* ent_cnt;           // [E] genes of the genome in that pham
     const int32_t* ent_len;           // [E] their summed length
+    const uint2* ent_pair_len;        // [E] (pham, summed length) and
+    const uint2* ent_pair_cnt;        // [E] (pham, gene count): one 8-byte load per entry for k_sparse_tile64
     const int32_t* ent_gene;          // [E] first gene id (genes of an entry are consecutive)
     const int32_t* ent_pham;          // [E] pham id (ascending within a genome: the set bits of its bitmap row, in order)
     const uint32_t* ent_off;          // [N+1] entries of genome g = [ent_off[g], ent_off[g+1])
@@ -94,6 +96,7 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
                        double* lut, bool build_lut, int sh_dim, int tot_dim, hipStream_t st);
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
 int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st);   // pocp / af
+int pc_launch_pair_entries(const int32_t* pham, const int32_t* len, const int32_t* cnt, uint2* pair_len, uint2* pair_cnt, int64_t n, hipStream_t st);
 int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st); // pocp / af, large matrices
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);

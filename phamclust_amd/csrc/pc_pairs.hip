@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_sparse_tile(PcDev d, PcShard sh, double
     // phase, not one per entry -- with the loads inside the loops a tile took 52 of them back to back and the kernel was
     // slower than the walker), then works on LDS only.
     const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    const int32_t* __restrict__ val = MODE == PCW_POCP ? d.ent_cnt : d.ent_len;
+    const uint2* __restrict__ ent = MODE == PCW_POCP ? d.ent_pair_cnt : d.ent_pair_len;
     for (int p0 = 0; p0 < d.Wb * 64; p0 += CH) {
         const int w0 = p0 >> 6, w1 = min(d.Wb, (p0 + CH) >> 6);
         __syncthreads();                                                            // g_s, g_t, acc visible / previous chunk done
@@ -579,10 +579,10 @@ __global__ __launch_bounds__(256) void k_sparse_tile(PcDev d, PcShard sh, double
             for (uint32_t e0 = qb + sub; e0 < qe; e0 += 8 * SP_IT) {
                 int ph[SP_IT]; uint32_t vv[SP_IT], mm[SP_IT];
 #pragma unroll
-                for (int i = 0; i < SP_IT; ++i) {
-                    const bool in = e0 + 8 * i < qe;
-                    ph[i] = in ? d.ent_pham[e0 + 8 * i] - p0 : -1;
-                    vv[i] = in ? (uint32_t)val[e0 + 8 * i] : 0u;
+                for (int i = 0; i < SP_IT; ++i) {                                   // (pham, value) in one 8-byte load
+                    const uint2 x = e0 + 8 * i < qe ? ent[e0 + 8 * i] : make_uint2((uint32_t)(p0 - 1), 0u);
+                    ph[i] = (int)x.x - p0;
+                    vv[i] = x.y;
                 }
 #pragma unroll
                 for (int i = 0; i < SP_IT; ++i) mm[i] = ph[i] >= 0 ? colmask[ph[i]] : 0u;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
     uint32_t* acc = sp_lds + 2 * CH;                                               // [64 sources][65]
     __shared__ int g_s[S6_T], g_t[S6_T];                                           // genome of tile row r, -1: none
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int32_t* __restrict__ val = MODE == PCW_POCP ? d.ent_cnt : d.ent_len;
+    const uint2* __restrict__ ent = MODE == PCW_POCP ? d.ent_pair_cnt : d.ent_pair_len;      // (pham, value)
     // Unit n of the XCD-aware tile order goes to workgroup n mod gridDim (a multiple of 8, so a workgroup keeps to the tiles of
     // its XCD).  Tiles differ in cost by 10 x (a tile inside a cluster of related genomes shares ~85 phams per pair, one between
     // clusters ~3), so the deal must stay fine: measured at N = 20,000 with gridDim = m x the 512 resident workgroups, m = 1: 4.40 ms,
@@ -704,8 +704,9 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
             for (int b = 0; b < S6_B; ++b) {
                 const uint32_t es = lo_s[rr] + (uint32_t)(64 * b + lane), et = lo_t[rr] + (uint32_t)(64 * b + lane);
                 const bool is = es < hi_s[rr], it = et < hi_t[rr];
-                ph_s[rr][b] = is ? d.ent_pham[es] - p0 : -1; v_s[rr][b] = is ? (uint32_t)val[es] : 0u;
-                ph_t[rr][b] = it ? d.ent_pham[et] - p0 : -1; v_t[rr][b] = it ? (uint32_t)val[et] : 0u;
+                const uint2 xs = is ? ent[es] : make_uint2((uint32_t)(p0 - 1), 0u), xt = it ? ent[et] : make_uint2((uint32_t)(p0 - 1), 0u);
+                ph_s[rr][b] = (int)xs.x - p0; v_s[rr][b] = xs.y;
+                ph_t[rr][b] = (int)xt.x - p0; v_t[rr][b] = xt.y;
             }
         // one direction: the rows of one side build the masks, the rows of the other probe them.  TO_ROW: the probing rows are
         // the accumulator rows (sources probe), else its columns (targets probe)
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
                 for (int b = 0; b < S6_B; ++b) if (bph[rr][b] >= 0) atomicOr(&colmask[2 * bph[rr][b] + half], bit);
                 for (uint32_t e0 = blo[rr] + 64u * S6_B; e0 < bhi[rr]; e0 += 64u) {          // rows with more entries than the registers hold
                     const uint32_t e = e0 + (uint32_t)lane;
-                    if (e < bhi[rr]) atomicOr(&colmask[2 * (d.ent_pham[e] - p0) + half], bit);
+                    if (e < bhi[rr]) atomicOr(&colmask[2 * ((int)ent[e].x - p0) + half], bit);
                 }
             }
             __syncthreads();
@@ -755,7 +756,8 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
                 for (uint32_t e0 = qlo[rr] + 64u * S6_B; e0 < qhi[rr]; e0 += 64u) {
                     const uint32_t e = e0 + (uint32_t)lane;
                     const bool in = e < qhi[rr];
-                    hit(to_row, r, in ? d.ent_pham[e] - p0 : -1, in ? (uint32_t)val[e] : 0u, hs);
+                    const uint2 x = in ? ent[e] : make_uint2((uint32_t)(p0 - 1), 0u);
+                    hit(to_row, r, (int)x.x - p0, x.y, hs);
                 }
                 if (hs) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + lane : lane * S6_LD + r], hs);
             }
@@ -784,6 +786,18 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
     }
 }
 
+__global__ void k_pair_entries(const int32_t* __restrict__ pham, const int32_t* __restrict__ len, const int32_t* __restrict__ cnt,
+                               uint2* __restrict__ pair_len, uint2* __restrict__ pair_cnt, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) { pair_len[e] = make_uint2((uint32_t)pham[e], (uint32_t)len[e]); pair_cnt[e] = make_uint2((uint32_t)pham[e], (uint32_t)cnt[e]); }
+}
+int pc_launch_pair_entries(const int32_t* pham, const int32_t* len, const int32_t* cnt, uint2* pair_len, uint2* pair_cnt, int64_t n, hipStream_t st) {
+    if (n <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_pair_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pham, len, cnt, pair_len, pair_cnt, n);
+    if (hipGetLastError() != hipSuccess) { pc_set_error("k_pair_entries launch failed"); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
 int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
     // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators), else 4,096 at a time
@@ -792,8 +806,9 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
     const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
     static const unsigned resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(2 * cus + 7) / 8u * 8u; }();
-    // three units per workgroup (see the kernel), never fewer workgroups than fit the chip at once
-    const unsigned want = std::max(resident, ((n_units + 2u) / 3u + 7u) / 8u * 8u);
+    // three units per workgroup (see the kernel); small matrices: one unit each, up to four times the workgroups that fit the chip
+    // at once (N = 2,000: 0.158 ms with two units per workgroup, 0.129 with one)
+    const unsigned want = std::max(std::min(n_units, 4u * resident), ((n_units + 2u) / 3u + 7u) / 8u * 8u);
     dim3 grid(std::min(n_units, want)), block(64 * S6_WAVES);
     // (up to 78 KB of dynamic LDS: HIP on this hardware needs no opt-in above 64 KB -- the K4 launches take up to 160 KB the same way)
     if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile64<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
