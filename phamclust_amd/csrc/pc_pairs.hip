@@ -666,6 +666,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
     uint32_t* colmask = sp_lds;                                                    // [CH][2]
     uint32_t* acc = sp_lds + 2 * CH;                                               // [64 sources][65]
     __shared__ int g_s[S6_T], g_t[S6_T];                                           // genome of tile row r, -1: none
+    __shared__ long long tot_s[S6_T], tot_t[S6_T];                                 // its total (genes, resp. residues): the epilogue's denominators
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint2* __restrict__ ent = MODE == PCW_POCP ? d.ent_pair_cnt : d.ent_pair_len;      // (pham, value)
     // Unit n of the XCD-aware tile order goes to workgroup n mod gridDim (a multiple of 8, so a workgroup keeps to the tiles of
@@ -682,7 +683,11 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
     if (s0 >= pc_owned(sh, klast)) continue;
     // lane l looks at row l of either side: genome, then (per chunk) where its entries start and end
     const int gs_l = s0 + lane < d.N ? s0 + lane : -1, gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;
-    if (wave == 0) { g_s[lane] = gs_l; g_t[lane] = gt_l; }
+    if (wave == 0) {
+        g_s[lane] = gs_l; g_t[lane] = gt_l;
+        tot_s[lane] = gs_l < 0 ? 0 : (MODE == PCW_POCP ? (long long)d.ngen[gs_l] : (long long)d.tlen[gs_l]);
+        tot_t[lane] = gt_l < 0 ? 0 : (MODE == PCW_POCP ? (long long)d.ngen[gt_l] : (long long)d.tlen[gt_l]);
+    }
     for (int i = tid; i < S6_T * S6_LD; i += 64 * S6_WAVES) acc[i] = 0u;
     for (int p0 = 0; p0 < d.Wb * 64; p0 += CH) {
         const int w0 = p0 >> 6, w1 = min(d.Wb, (p0 + CH) >> 6);
@@ -776,10 +781,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
         if (s < 0 || t < 0 || s >= t) continue;
         const uint32_t cons = acc[ls * S6_LD + lt];
         double sim = 0.0;
-        if (cons) {
-            if (MODE == PCW_POCP) sim = (double)cons / (double)(d.ngen[s] + d.ngen[t]);    // metrics.py:104-110
-            else sim = (double)cons / (double)(d.tlen[s] + d.tlen[t]);                      // metrics.py:149-152
-        }
+        if (cons) sim = (double)cons / (double)(tot_s[ls] + tot_t[lt]);               // metrics.py:104-110 (pocp), 149-152 (af)
         out[pc_out_index(d, sh, s, t, k0 + lt, condensed)] = pc_finish(sim, as_distance);
     }
     __syncthreads();                                                                // the next tile clears acc and rewrites g_s, g_t
