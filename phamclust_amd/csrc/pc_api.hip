@@ -1251,7 +1251,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     // Which kernel fills a set metric (measured crossovers, `profiles/r03_p_sparse64_record.txt`; PC_SET_KERNEL =
     // popc | sparse | sparse64 | walker forces one for A/B runs and for the tests that keep every one of them honest):
     //   gcs, jc          popcount tiles
-    //   pocp             popcount tiles + paralog excess, from ~4,500 genomes the 64 x 64 sparse tile kernel
+    //   pocp             popcount tiles + paralog excess, from ~2,500 genomes the 64 x 64 sparse tile kernel
     //   af               the 32 x 32 sparse tile kernel below ~1,900 genomes, the 64 x 64 one above
     // The 64 x 64 kernel takes "sum == 0" for "no shared pham" and sums in 32 bits: it needs every entry value >= 1 (a
     // genome with an empty translation fails that for af) and genome totals below 2^32; else af falls back to the
@@ -1262,7 +1262,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         const char* set_force = getenv("PC_SET_KERNEL");                   // (read per fill: the tests switch it between launches)
         const int64_t area = (int64_t)d.N * c->shard.nown;
         const bool s64_ok = metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
-        if (metric == PC_POCP) kernel = (s64_ok && area > (int64_t)4500 * 4500) ? K_SPARSE64 : K_POPC;
+        if (metric == PC_POCP) kernel = (s64_ok && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
         if (set_force) {

@@ -716,6 +716,8 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
         // one direction: the rows of one side build the masks, the rows of the other probe them.  TO_ROW: the probing rows are
         // the accumulator rows (sources probe), else its columns (targets probe)
         auto hit = [&](auto to_row, int r, int ph, uint32_t v, uint32_t& hs) {
+            // pocp: the entry's gene count c adds c + 1 where the sources probe and c - 1 where the targets do (see below)
+            if constexpr (MODE == PCW_POCP) v = decltype(to_row)::value ? v + 1u : v - 1u;
             uint2 m = make_uint2(0u, 0u);
             if (ph >= 0) m = *(const uint2*)&colmask[2 * ph];
             const int pc = __popc(m.x) + __popc(m.y);
@@ -762,14 +764,23 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
                     const uint32_t e = e0 + (uint32_t)lane;
                     const bool in = e < qhi[rr];
                     const uint2 x = in ? ent[e] : make_uint2((uint32_t)(p0 - 1), 0u);
-                    hit(to_row, r, (int)x.x - p0, x.y, hs);
+                    hit(to_row, r, (MODE == PCW_POCP && !decltype(to_row)::value && x.y <= 1u) ? -1 : (int)x.x - p0, x.y, hs);
                 }
                 if (hs) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + lane : lane * S6_LD + r], hs);
             }
             __syncthreads();                                                        // probes done before the masks are cleared again
         };
         direction(std::true_type{}, ph_t, lo_t, hi_t, ph_s, v_s, lo_s, hi_s);       // masks over the targets, the sources' entries probe
-        direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);      // the other way round
+        if constexpr (MODE == PCW_POCP) {
+            // conserved(s, t) = sum over shared phams of cnt_s + cnt_t = sum (cnt_s + 1) + sum (cnt_t - 1): the first direction added
+            // cnt_s + 1 per hit; in the second only the targets' PARALOG entries (cnt_t > 1: ~6 %) have anything to add, the rest
+            // stay out of the probes (the masks over the sources are still built from all their entries)
+#pragma unroll
+            for (int rr = 0; rr < S6_RPW; ++rr)
+#pragma unroll
+                for (int b = 0; b < S6_B; ++b) if (v_t[rr][b] <= 1u) ph_t[rr][b] = -1;       // (the targets' masks are not built again)
+            direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);
+        } else direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);      // the other way round
     }
     // finish: 4,096 pairs, 8 per thread; consecutive lanes run along the output's contiguous direction
 #pragma unroll 4
