@@ -650,9 +650,14 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 //   * a probe that hits more is BROADCAST (readlane): its 64-bit mask becomes the EXEC mask of one v_add into a register
 //     the 64 lanes hold for the 64 rows of the other side -- no divergence, no LDS traffic; the register is flushed into
 //     the LDS accumulators once per probing row.
+//   * an entry is ONE 8-byte load: (pham, value) pairs, made on the device at upload (k_pair_entries); the epilogue's
+//     denominators come from LDS (64 + 64 totals per tile);
+//   * pocp adds count + 1 where the sources probe and count - 1 where the targets do, so in the second direction only the
+//     targets' paralog entries (~6 %) probe at all.
 // Accumulators: u32 in LDS, row stride 65 (both directions conflict free).  "No shared pham" is "sum == 0": the host uses
 // this kernel only when every entry value is >= 1 (always true for gene counts; for summed lengths unless a translation
-// is empty) and every genome's total stays below 2^32 -- otherwise the walker runs.
+// is empty) and every genome's total stays below 2^31 -- otherwise the 32 x 32 kernel / the walker (af) or the popcount
+// tiles (pocp) run.
 // ---------------------------------------------------------------------------------
 #define S6_T 64
 #define S6_LD 65
