@@ -21,6 +21,7 @@
 #include <new>
 #include <numeric>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "pc_common.h"
@@ -128,6 +129,7 @@ struct pc_ctx {
     std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
     int max_gene_len = 0, min_gene_len = 0, max_nph = 0, max_ngen = 0;
     int64_t max_tlen = 0;                    // largest summed translation length of a genome
+    double avg_shared = 0.0;                 // phams an average genome pair shares (pocp's kernel choice)
     // kernel-variant classes over column genes
     int ncls_all = 0;                       // launch classes: variant * 4 + lanes-per-segment bucket, last = general kernel
     std::vector<int32_t> cls_max_lb;        // [ncls_all] longest column sequence that can land in the class (LDS size of its launch)
@@ -442,6 +444,19 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     for (int s = 0; s < N; ++s) {
         if (bad[s] == 1) { pc_set_error("pc_upload: genome %d: a gene's pham id is out of order or not in the bitmap", s); return PC_ERR_ARG; }
         if (bad[s] == 2) { pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG; }
+    }
+    {   // phams an average genome pair shares = sum over phams of holders (holders - 1) / (N (N - 1)): what decides between pocp's kernels
+        std::vector<uint32_t> holders((size_t)std::max(P, 1), 0u);
+        std::mutex merge;
+        parallel_chunks((int64_t)E, [&](int64_t e0, int64_t e1) {
+            std::vector<uint32_t> mine((size_t)std::max(P, 1), 0u);
+            for (int64_t e = e0; e < e1; ++e) ++mine[(size_t)ent_pham[e]];
+            std::lock_guard<std::mutex> lock(merge);
+            for (int p2 = 0; p2 < P; ++p2) holders[(size_t)p2] += mine[(size_t)p2];
+        }, 1 << 17);
+        double inc = 0.0;
+        for (uint32_t n : holders) inc += (double)n * (double)(n > 0 ? n - 1 : 0);
+        c->avg_shared = N > 1 ? inc / ((double)N * (double)(N - 1)) : 0.0;
     }
     // paralog lists (pocp): a genome's entries with more than one gene, as (pham, count - 1).  conserved proteins of a pair =
     // 2 x shared phams + the excess counts of the shared paralog phams, and only ~6 % of the entries are paralogs
@@ -1251,7 +1266,8 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     // Which kernel fills a set metric (measured crossovers, `profiles/r03_p_sparse64_record.txt`; PC_SET_KERNEL =
     // popc | sparse | sparse64 | walker forces one for A/B runs and for the tests that keep every one of them honest):
     //   gcs, jc          popcount tiles
-    //   pocp             popcount tiles + paralog excess, from ~2,500 genomes the 64 x 64 sparse tile kernel
+    //   pocp             popcount tiles + paralog excess; from ~2,500 genomes the 64 x 64 sparse tile kernel where pairs share few
+    //                    enough of the phams (below)
     //   af               the 32 x 32 sparse tile kernel below ~1,900 genomes, the 64 x 64 one above
     // The 64 x 64 kernel takes "sum == 0" for "no shared pham" and sums in 32 bits: it needs every entry value >= 1 (a
     // genome with an empty translation fails that for af) and genome totals below 2^32; else af falls back to the
@@ -1262,7 +1278,14 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         const char* set_force = getenv("PC_SET_KERNEL");                   // (read per fill: the tests switch it between launches)
         const int64_t area = (int64_t)d.N * c->shard.nown;
         const bool s64_ok = metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
-        if (metric == PC_POCP) kernel = (s64_ok && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
+        if (metric == PC_POCP) {
+            // popcount tiles cost ~ pairs x bitmap words, the sparse tiles ~ pairs x (a constant + the phams a pair shares): measured on
+            // synth(5000, P) for P = 300 ... 5,000 (0.15 + 0.002 W against 0.207 + 0.0085 shared, ms), the sparse tiles win where
+            // W > 28 + 4.3 x shared -- the synthetic collection (79 words, 2.85 shared) yes, one with 300 phams (5 words, 34 shared)
+            // three times no.  `shared` of an average pair = sum over phams of n_p (n_p - 1) / (N (N - 1)), counted at upload.
+            const bool sparse_pays = (double)d.Wb > 28.0 + 4.3 * std::max(c->avg_shared, 0.0);
+            kernel = (s64_ok && sparse_pays && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
+        }
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
         if (set_force) {
