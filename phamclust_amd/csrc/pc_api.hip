@@ -1263,39 +1263,47 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     as_distance = as_distance ? 1 : 0;
     PC_HIP(hipEventRecord(c->ev[0], st));
 
-    // Which kernel fills a set metric (measured crossovers, `profiles/r03_p_sparse64_record.txt`; PC_SET_KERNEL =
-    // popc | sparse | sparse64 | walker forces one for A/B runs and for the tests that keep every one of them honest):
-    //   gcs, jc          popcount tiles
+    // Which kernel fills a set metric (measured crossovers, `profiles/r03_p_sparse64_record.txt`, `r03_z_pocp_kernel_by_density.txt`;
+    // PC_SET_KERNEL = popc | sparse | sparse64 | walker forces one where it exists, for A/B runs and for the tests that keep every
+    // one of them honest):
+    //   gcs, jc          popcount tiles; a collection of many phams (long bitmap rows, few of them shared): the 64 x 64 sparse tile
+    //                    kernel in its counting mode
     //   pocp             popcount tiles + paralog excess; from ~2,500 genomes the 64 x 64 sparse tile kernel where pairs share few
-    //                    enough of the phams (below)
+    //                    enough of the phams
     //   af               the 32 x 32 sparse tile kernel below ~1,900 genomes, the 64 x 64 one above
+    // The popcount tiles cost ~ pairs x bitmap words W, the sparse tiles ~ pairs x (a constant + the phams a pair shares).  Measured on
+    // synth(5000, P), P = 300 ... 40,000, in ms: pocp 0.15 + 0.002 W against 0.207 + 0.0085 shared (sparse wins where W > 28 + 4.3 shared:
+    // the synthetic collection's 79 words and 2.85 shared phams yes, 300 phams -- 5 words, 34 shared -- three times no); gcs / jc
+    // 0.05 + 0.0014 W against 0.155 + 0.0004 W + ~0.005 shared (W > 113 + 5.4 shared: from ~7,500 phams; at 40,000: 0.43 against 0.90).
+    // `shared` of an average pair = sum over phams of n_p (n_p - 1) / (N (N - 1)), counted at upload.
     // The 64 x 64 kernel takes "sum == 0" for "no shared pham" and sums in 32 bits: it needs every entry value >= 1 (a
-    // genome with an empty translation fails that for af) and genome totals below 2^32; else af falls back to the
+    // genome with an empty translation fails that for af) and genome totals below 2^31; else af falls back to the
     // 32 x 32 kernel / the shared-pham walker (crossover ~3,500 genomes), pocp to the popcount tiles.
     enum { K_POPC, K_SPARSE32, K_SPARSE64, K_WALKER };
     int kernel = K_POPC;
-    if (metric == PC_POCP || metric == PC_AF) {
+    {
         const char* set_force = getenv("PC_SET_KERNEL");                   // (read per fill: the tests switch it between launches)
         const int64_t area = (int64_t)d.N * c->shard.nown;
-        const bool s64_ok = metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
-        if (metric == PC_POCP) {
-            // popcount tiles cost ~ pairs x bitmap words, the sparse tiles ~ pairs x (a constant + the phams a pair shares): measured on
-            // synth(5000, P) for P = 300 ... 5,000 (0.15 + 0.002 W against 0.207 + 0.0085 shared, ms), the sparse tiles win where
-            // W > 28 + 4.3 x shared -- the synthetic collection (79 words, 2.85 shared) yes, one with 300 phams (5 words, 34 shared)
-            // three times no.  `shared` of an average pair = sum over phams of n_p (n_p - 1) / (N (N - 1)), counted at upload.
-            const bool sparse_pays = (double)d.Wb > 28.0 + 4.3 * std::max(c->avg_shared, 0.0);
-            kernel = (s64_ok && sparse_pays && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
-        }
+        const double shared = std::max(c->avg_shared, 0.0);
+        const bool counts = metric == PC_GCS || metric == PC_JC;
+        const bool s64_ok = counts ? c->max_nph < (1 << 30) : metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
+        if (counts) kernel = ((double)d.Wb > 113.0 + 5.4 * shared && area >= (int64_t)3000 * 3000) ? K_SPARSE64 : K_POPC;
+        else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
         if (set_force) {
-            if (!strcmp(set_force, "popc") && metric == PC_POCP) kernel = K_POPC;
-            else if (!strcmp(set_force, "sparse")) kernel = K_SPARSE32;
+            if (!strcmp(set_force, "popc") && metric != PC_AF) kernel = K_POPC;
+            else if (!strcmp(set_force, "sparse") && !counts) kernel = K_SPARSE32;
             else if (!strcmp(set_force, "sparse64") && s64_ok) kernel = K_SPARSE64;
-            else if (!strcmp(set_force, "walker")) kernel = K_WALKER;
+            else if (!strcmp(set_force, "walker") && !counts) kernel = K_WALKER;
         }
     }
-    if (metric == PC_GCS || metric == PC_JC || (metric == PC_POCP && kernel == K_POPC)) {
+    if ((metric == PC_GCS || metric == PC_JC) && kernel == K_SPARSE64) {
+        rc = pc_launch_sparse64(metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC, d, c->shard, out, as_distance, condensed, st);
+        if (rc != PC_OK) return rc;
+        PC_HIP(hipEventRecord(c->ev[3], st));
+        local.n_chunks = 1;
+    } else if (metric == PC_GCS || metric == PC_JC || (metric == PC_POCP && kernel == K_POPC)) {
         // epilogue table: gcs / jc over (shared, nph_s + nph_t), at most (max_nph+1) x (2 max_nph+1) doubles; pocp over
         // (conserved, ngen_s + ngen_t), (2 max_ngen+1)^2; skipped when huge.  It depends on (metric, as_distance, that maximum)
         // only, so it is rebuilt only when one of them changes.

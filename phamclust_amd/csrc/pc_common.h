@@ -62,6 +62,7 @@ struct PcTaskPlan {
 
 // walker modes (pc_pairs.hip)
 enum { PCW_POCP = 0, PCW_AF = 1, PCW_COUNT = 2, PCW_ENUM = 3, PCW_AAI = 4, PCW_PEQ = 5 };
+enum { PCW_SPARSE_GCS = 10, PCW_SPARSE_JC = 11 };   // k_sparse_tile64 only: shared-pham counts, one direction
 
 struct PcWalkArgs {
     // COUNT

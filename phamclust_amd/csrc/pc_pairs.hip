@@ -664,6 +664,8 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 #define S6_WAVES 8
 #define S6_RPW (S6_T / S6_WAVES)                                  // rows (of either side) a wave owns
 #define S6_B 2                                                    // 64-entry batches of a row held in registers
+#define S6_GCS PCW_SPARSE_GCS                                     // MODE values beside PCW_POCP / PCW_AF: shared-pham counts only (gcs, jc)
+#define S6_JC PCW_SPARSE_JC
 #define S6_SUPER 16                                               // super-tile edge in tiles: 2 x 1,024 rows' entry lists = 1.6 MB of an XCD's 4-MB L2
 template <int MODE>
 __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
@@ -673,6 +675,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
     __shared__ int g_s[S6_T], g_t[S6_T];                                           // genome of tile row r, -1: none
     __shared__ long long tot_s[S6_T], tot_t[S6_T];                                 // its total (genes, resp. residues): the epilogue's denominators
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool COUNT = MODE >= S6_GCS;                                          // gcs / jc: |S n T| only -- every hit adds 1, and ONE direction does it
     const uint2* __restrict__ ent = MODE == PCW_POCP ? d.ent_pair_cnt : d.ent_pair_len;      // (pham, value)
     // Unit n of the XCD-aware tile order goes to workgroup n mod gridDim (a multiple of 8, so a workgroup keeps to the tiles of
     // its XCD).  Tiles differ in cost by 10 x (a tile inside a cluster of related genomes shares ~85 phams per pair, one between
@@ -690,8 +693,8 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
     const int gs_l = s0 + lane < d.N ? s0 + lane : -1, gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;
     if (wave == 0) {
         g_s[lane] = gs_l; g_t[lane] = gt_l;
-        tot_s[lane] = gs_l < 0 ? 0 : (MODE == PCW_POCP ? (long long)d.ngen[gs_l] : (long long)d.tlen[gs_l]);
-        tot_t[lane] = gt_l < 0 ? 0 : (MODE == PCW_POCP ? (long long)d.ngen[gt_l] : (long long)d.tlen[gt_l]);
+        tot_s[lane] = gs_l < 0 ? 0 : (COUNT ? (long long)d.nph[gs_l] : MODE == PCW_POCP ? (long long)d.ngen[gs_l] : (long long)d.tlen[gs_l]);
+        tot_t[lane] = gt_l < 0 ? 0 : (COUNT ? (long long)d.nph[gt_l] : MODE == PCW_POCP ? (long long)d.ngen[gt_l] : (long long)d.tlen[gt_l]);
     }
     for (int i = tid; i < S6_T * S6_LD; i += 64 * S6_WAVES) acc[i] = 0u;
     for (int p0 = 0; p0 < d.Wb * 64; p0 += CH) {
@@ -714,9 +717,14 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
             for (int b = 0; b < S6_B; ++b) {
                 const uint32_t es = lo_s[rr] + (uint32_t)(64 * b + lane), et = lo_t[rr] + (uint32_t)(64 * b + lane);
                 const bool is = es < hi_s[rr], it = et < hi_t[rr];
-                const uint2 xs = is ? ent[es] : make_uint2((uint32_t)(p0 - 1), 0u), xt = it ? ent[et] : make_uint2((uint32_t)(p0 - 1), 0u);
-                ph_s[rr][b] = (int)xs.x - p0; v_s[rr][b] = xs.y;
-                ph_t[rr][b] = (int)xt.x - p0; v_t[rr][b] = xt.y;
+                if constexpr (COUNT) {
+                    ph_s[rr][b] = is ? d.ent_pham[es] - p0 : -1; v_s[rr][b] = 1u;
+                    ph_t[rr][b] = it ? d.ent_pham[et] - p0 : -1; v_t[rr][b] = 1u;
+                } else {
+                    const uint2 xs = is ? ent[es] : make_uint2((uint32_t)(p0 - 1), 0u), xt = it ? ent[et] : make_uint2((uint32_t)(p0 - 1), 0u);
+                    ph_s[rr][b] = (int)xs.x - p0; v_s[rr][b] = xs.y;
+                    ph_t[rr][b] = (int)xt.x - p0; v_t[rr][b] = xt.y;
+                }
             }
         // one direction: the rows of one side build the masks, the rows of the other probe them.  TO_ROW: the probing rows are
         // the accumulator rows (sources probe), else its columns (targets probe)
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
                 for (int b = 0; b < S6_B; ++b) if (bph[rr][b] >= 0) atomicOr(&colmask[2 * bph[rr][b] + half], bit);
                 for (uint32_t e0 = blo[rr] + 64u * S6_B; e0 < bhi[rr]; e0 += 64u) {          // rows with more entries than the registers hold
                     const uint32_t e = e0 + (uint32_t)lane;
-                    if (e < bhi[rr]) atomicOr(&colmask[2 * ((int)ent[e].x - p0) + half], bit);
+                    if (e < bhi[rr]) atomicOr(&colmask[2 * (d.ent_pham[e] - p0) + half], bit);
                 }
             }
             __syncthreads();
@@ -768,7 +776,8 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
                 for (uint32_t e0 = qlo[rr] + 64u * S6_B; e0 < qhi[rr]; e0 += 64u) {
                     const uint32_t e = e0 + (uint32_t)lane;
                     const bool in = e < qhi[rr];
-                    const uint2 x = in ? ent[e] : make_uint2((uint32_t)(p0 - 1), 0u);
+                    uint2 x = make_uint2((uint32_t)(p0 - 1), 0u);
+                    if (in) { if constexpr (COUNT) x = make_uint2((uint32_t)d.ent_pham[e], 1u); else x = ent[e]; }
                     hit(to_row, r, (MODE == PCW_POCP && !decltype(to_row)::value && x.y <= 1u) ? -1 : (int)x.x - p0, x.y, hs);
                 }
                 if (hs) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + lane : lane * S6_LD + r], hs);
@@ -776,7 +785,9 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
             __syncthreads();                                                        // probes done before the masks are cleared again
         };
         direction(std::true_type{}, ph_t, lo_t, hi_t, ph_s, v_s, lo_s, hi_s);       // masks over the targets, the sources' entries probe
-        if constexpr (MODE == PCW_POCP) {
+        if constexpr (COUNT) {
+            // |S n T| is symmetric: the sources' probes have counted it
+        } else if constexpr (MODE == PCW_POCP) {
             // conserved(s, t) = sum over shared phams of cnt_s + cnt_t = sum (cnt_s + 1) + sum (cnt_t - 1): the first direction added
             // cnt_s + 1 per hit; in the second only the targets' PARALOG entries (cnt_t > 1: ~6 %) have anything to add, the rest
             // stay out of the probes (the masks over the sources are still built from all their entries)
@@ -796,6 +807,10 @@ __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShar
         const int s = g_s[ls], t = g_t[lt];
         if (s < 0 || t < 0 || s >= t) continue;
         const uint32_t cons = acc[ls * S6_LD + lt];
+        if constexpr (COUNT) {                                                       // metrics.py:45-53 (gcs), 75-80 (jc)
+            out[pc_out_index(d, sh, s, t, k0 + lt, condensed)] = pc_set_value<MODE == S6_GCS ? PC_GCS : PC_JC>((int)cons, (int)(tot_s[ls] + tot_t[lt]), as_distance);
+            continue;
+        }
         double sim = 0.0;
         if (cons) sim = (double)cons / (double)(tot_s[ls] + tot_t[lt]);               // metrics.py:104-110 (pocp), 149-152 (af)
         out[pc_out_index(d, sh, s, t, k0 + lt, condensed)] = pc_finish(sim, as_distance);
@@ -829,7 +844,9 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     const unsigned want = std::max(std::min(n_units, 4u * resident), ((n_units + 2u) / 3u + 7u) / 8u * 8u);
     dim3 grid(std::min(n_units, want)), block(64 * S6_WAVES);
     // (up to 78 KB of dynamic LDS: HIP on this hardware needs no opt-in above 64 KB -- the K4 launches take up to 160 KB the same way)
-    if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile64<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
+    if (mode == S6_GCS) hipLaunchKernelGGL(k_sparse_tile64<S6_GCS>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
+    else if (mode == S6_JC) hipLaunchKernelGGL(k_sparse_tile64<S6_JC>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
+    else if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile64<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
     else hipLaunchKernelGGL(k_sparse_tile64<PCW_AF>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_tile64 launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }

@@ -1208,15 +1208,19 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
             gpu_ctx.upload(packed, residues=False)
             for (m, dist), w in want.items():
                 assert np.array_equal(gpu_ctx.fill(m, dist), w), (kernel, m, dist)
+            if kernel in ("popc", "sparse64"):                               # gcs / jc: popcount tiles, or the sparse tiles' counting mode
+                for m in ("gcs", "jc"):
+                    for dist in (True, False):
+                        assert np.array_equal(gpu_ctx.fill(m, dist), O.fill(packed, m, dist)), (kernel, m, dist)
             gpu_ctx.set_shard(1, 3)
             t_rank, t_lbase = gpu_ctx.shard_table()
             n = packed.n_genomes
-            for m in ("pocp", "af"):
+            for m in ("pocp", "af") + (("jc",) if kernel in ("popc", "sparse64") else ()):
                 buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
                 gpu_ctx.fill_shard_dev(m, True, buf.data_ptr(), stream)
                 torch.cuda.synchronize()
                 got = buf.cpu().numpy()
-                w = want[(m, True)]
+                w = want[(m, True)] if (m, True) in want else O.fill(packed, m, True)
                 for t in range(1, n):
                     if t_rank[t] != 1:
                         continue
@@ -1228,7 +1232,7 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
         mid = _set_kernel_case(rng, 120, 25000, wide_rows=(9,))
         assert 5952 < mid.words_per_row * 64 <= 7680
         gpu_ctx.upload(mid, residues=False)
-        for m in ("pocp", "af"):
+        for m in ("pocp", "af", "gcs", "jc"):
             assert np.array_equal(gpu_ctx.fill(m), O.fill(mid, m)), m
         # an empty translation makes "sum == 0" ambiguous: the 64 x 64 kernel must step aside, whatever was asked for
         odd = _set_kernel_case(rng, 40, 300, empty_translation_in=2)
