@@ -663,11 +663,13 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 #define S6_LD 65
 #define S6_WAVES 8
 #define S6_RPW (S6_T / S6_WAVES)                                  // rows (of either side) a wave owns
-#define S6_B 2                                                    // 64-entry batches of a row held in registers
 #define S6_GCS PCW_SPARSE_GCS                                     // MODE values beside PCW_POCP / PCW_AF: shared-pham counts only (gcs, jc)
 #define S6_JC PCW_SPARSE_JC
 #define S6_SUPER 16                                               // super-tile edge in tiles: 2 x 1,024 rows' entry lists = 1.6 MB of an XCD's 4-MB L2
-template <int MODE>
+// S6_B: 64-entry batches of a row held in registers -- 2 when one mask chunk holds all phams (a row's ~100 entries), 1 when the
+// phams take several chunks (a row then has a few dozen entries per chunk; half the loads and probe steps, and registers for a
+// third workgroup per CU)
+template <int MODE, int S6_B>
 __global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
     uint32_t* colmask = sp_lds;                                                    // [CH][2]
@@ -833,9 +835,11 @@ int pc_launch_pair_entries(const int32_t* pham, const int32_t* len, const int32_
 
 int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
-    // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators), else 4,096 at a time
+    // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators: 7,680 phams), else the
+    // fewest equal chunks of at most that many
     const int P64 = d.Wb * 64;
-    const int CH = P64 <= 7680 ? P64 : 4096;
+    const int n_chunks = (P64 + 7679) / 7680;
+    const int CH = (P64 / 64 + n_chunks - 1) / n_chunks * 64;                       // equal chunks (synth(20000,20000): 5 x 4,096: jc 2.67 ms, 3 x 6,720: 2.5)
     const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
     const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
     static const unsigned resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(2 * cus + 7) / 8u * 8u; }();
@@ -844,10 +848,13 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     const unsigned want = std::max(std::min(n_units, 4u * resident), ((n_units + 2u) / 3u + 7u) / 8u * 8u);
     dim3 grid(std::min(n_units, want)), block(64 * S6_WAVES);
     // (up to 78 KB of dynamic LDS: HIP on this hardware needs no opt-in above 64 KB -- the K4 launches take up to 160 KB the same way)
-    if (mode == S6_GCS) hipLaunchKernelGGL(k_sparse_tile64<S6_GCS>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
-    else if (mode == S6_JC) hipLaunchKernelGGL(k_sparse_tile64<S6_JC>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
-    else if (mode == PCW_POCP) hipLaunchKernelGGL(k_sparse_tile64<PCW_POCP>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
-    else hipLaunchKernelGGL(k_sparse_tile64<PCW_AF>, grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units);
+#define S6_LAUNCH(M, B) hipLaunchKernelGGL((k_sparse_tile64<M, B>), grid, block, lds, st, d, sh, out, as_distance, condensed, CH, n_units)
+    const bool chunked = CH < P64;
+    if (mode == S6_GCS) { if (chunked) S6_LAUNCH(S6_GCS, 1); else S6_LAUNCH(S6_GCS, 2); }
+    else if (mode == S6_JC) { if (chunked) S6_LAUNCH(S6_JC, 1); else S6_LAUNCH(S6_JC, 2); }
+    else if (mode == PCW_POCP) { if (chunked) S6_LAUNCH(PCW_POCP, 1); else S6_LAUNCH(PCW_POCP, 2); }
+    else { if (chunked) S6_LAUNCH(PCW_AF, 1); else S6_LAUNCH(PCW_AF, 2); }
+#undef S6_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_tile64 launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
