@@ -838,7 +838,11 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators: 7,680 phams), else the
     // fewest equal chunks of at most that many
     const int P64 = d.Wb * 64;
-    const int n_chunks = (P64 + 7679) / 7680;
+    // ... except that gcs / jc / af split even 2,048 ... 7,680 phams in two: their one-batch instances need 59 / 78 registers, and
+    // with 20 KB of masks three workgroups fit a CU instead of two (N = 20,000, 5,056 phams: jc 2.06 -> 1.79 ms, af 2.89 -> 2.60;
+    // pocp's instance needs 84 registers, stays at two workgroups and loses: 2.63 -> 3.08)
+    int n_chunks = (P64 + 7679) / 7680;
+    if (n_chunks == 1 && mode != PCW_POCP && P64 >= 2048 && (int64_t)d.N * sh.nown >= (int64_t)4000 * 4000) n_chunks = 2;   // (below: af at N = 3,000 0.150 ms whole, 0.165 split)
     const int CH = (P64 / 64 + n_chunks - 1) / n_chunks * 64;                       // equal chunks (synth(20000,20000): 5 x 4,096: jc 2.67 ms, 3 x 6,720: 2.5)
     const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
     const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
