@@ -668,9 +668,9 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 #define S6_SUPER 16                                               // super-tile edge in tiles: 2 x 1,024 rows' entry lists = 1.6 MB of an XCD's 4-MB L2
 // S6_B: 64-entry batches of a row held in registers -- 2 when one mask chunk holds all phams (a row's ~100 entries), 1 when the
 // phams take several chunks (a row then has a few dozen entries per chunk; half the loads and probe steps, and registers for a
-// third workgroup per CU)
+// third workgroup per CU: the launch bound asks for six waves per SIMD there)
 template <int MODE, int S6_B>
-__global__ __launch_bounds__(64 * S6_WAVES) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
+__global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
     uint32_t* colmask = sp_lds;                                                    // [CH][2]
     uint32_t* acc = sp_lds + 2 * CH;                                               // [64 sources][65]
@@ -838,11 +838,11 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators: 7,680 phams), else the
     // fewest equal chunks of at most that many
     const int P64 = d.Wb * 64;
-    // ... except that gcs / jc / af split even 2,048 ... 7,680 phams in two: their one-batch instances need 59 / 78 registers, and
-    // with 20 KB of masks three workgroups fit a CU instead of two (N = 20,000, 5,056 phams: jc 2.06 -> 1.79 ms, af 2.89 -> 2.60;
-    // pocp's instance needs 84 registers, stays at two workgroups and loses: 2.63 -> 3.08)
+    // ... except that 2,048 ... 7,680 phams are split in two from ~4,000 genomes: the one-batch instances need 59 (gcs / jc), 78 (af) and --
+    // held there by the launch bound, 4 dwords of scratch -- 80 (pocp) registers, and with 20 KB of masks three workgroups fit a CU instead
+    // of two (N = 20,000, 5,056 phams: jc 2.06 -> 1.79 ms, af 2.89 -> 2.60, pocp 2.61 -> 2.42; below: af at N = 3,000 0.150 ms whole, 0.165 split)
     int n_chunks = (P64 + 7679) / 7680;
-    if (n_chunks == 1 && mode != PCW_POCP && P64 >= 2048 && (int64_t)d.N * sh.nown >= (int64_t)4000 * 4000) n_chunks = 2;   // (below: af at N = 3,000 0.150 ms whole, 0.165 split)
+    if (n_chunks == 1 && P64 >= 2048 && (int64_t)d.N * sh.nown >= (int64_t)4000 * 4000) n_chunks = 2;
     const int CH = (P64 / 64 + n_chunks - 1) / n_chunks * 64;                       // equal chunks (synth(20000,20000): 5 x 4,096: jc 2.67 ms, 3 x 6,720: 2.5)
     const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
     const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
