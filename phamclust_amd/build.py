@@ -27,6 +27,10 @@ HIP_SOURCES = sorted({u[0] for u in HIP_UNITS})
 HIP_LIB = os.path.join(CSRC, "libphamclust_hip.so")
 SYNTH_LIB = os.path.join(CSRC, "libpc_synth.so")
 PACK_LIB = os.path.join(CSRC, "libpc_pack.so")
+# Every unit is compiled with -cuid=<its object's name>: hipcc otherwise derives the compilation-unit id from the source file's
+# ABSOLUTE path and puts it into the device code object, so the same sources built in another directory (a scratch checkout on
+# the GPU box) give other bytes -- and bench.py keys the PMC traffic record (profiles/traffic.json) by the hash of exactly
+# those bytes.  (-fuse-cuid=none would do the same but gives every unit the one symbol __hip_cuid_: they no longer link.)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -46,7 +50,7 @@ def build_hip(force=False, verbose=False):
         src_path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, obj_name)
         if force or _stale(obj, [src_path] + headers):
-            cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", src_path, "-o", obj]
+            cmd = [hipcc] + HIPCC_FLAGS + ["-cuid=" + os.path.splitext(obj_name)[0]] + extra + ["-c", src_path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))          # the translation units compile side by side
