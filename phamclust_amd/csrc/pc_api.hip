@@ -365,7 +365,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     const size_t o_bitmap = place((size_t)N * Wstride * 8), o_rankpre = place((size_t)N * W * 4), o_gene_len = place((size_t)std::max(G, 1) * 4),
                  o_ent_off = place(((size_t)N + 1) * 4), o_nph = place((size_t)N * 4), o_ngen = place((size_t)N * 4), o_tlen = place((size_t)N * 8);
     const size_t o_ent = off;                                           // four entry arrays of E <= G elements follow
-    const size_t cap_bytes = o_ent + 6 * (((size_t)std::max(G, 1) * 4 + 255) & ~(size_t)255) + (((size_t)N + 1) * 4 + 255);   // + the paralog lists
+    const size_t cap_bytes = o_ent + 6 * (((size_t)std::max(G, 1) * 4 + 255) & ~(size_t)255) + (((size_t)N + 1) * 4 + 255) + (size_t)std::max(P, 1) * 4 + 1024;   // + the paralog lists + the dense-id table
     if (cap_bytes > c->h_stage_cap) {
         if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
         const size_t want = cap_bytes + cap_bytes / 8;
@@ -445,8 +445,9 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         if (bad[s] == 1) { pc_set_error("pc_upload: genome %d: a gene's pham id is out of order or not in the bitmap", s); return PC_ERR_ARG; }
         if (bad[s] == 2) { pc_set_error("pc_upload: genome %d: bitmap/nph/ngen/tlen disagree with its gene list", s); return PC_ERR_ARG; }
     }
-    {   // phams an average genome pair shares = sum over phams of holders (holders - 1) / (N (N - 1)): what decides between pocp's kernels
-        std::vector<uint32_t> holders((size_t)std::max(P, 1), 0u);
+    // phams an average genome pair shares = sum over phams of holders (holders - 1) / (N (N - 1)): what decides between the set metrics' kernels
+    std::vector<uint32_t> holders((size_t)std::max(P, 1), 0u);
+    {
         std::mutex merge;
         parallel_chunks((int64_t)E, [&](int64_t e0, int64_t e1) {
             std::vector<uint32_t> mine((size_t)std::max(P, 1), 0u);
@@ -478,11 +479,24 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         para_off[N] = (uint32_t)at;
         c->max_ngen = max_ngen;
     }
-    // (pham, summed length) and (pham, gene count) side by side -- the 64 x 64 sparse tile kernel takes an entry with one 8-byte
-    // load -- are made on the device from the three arrays above (k_pair_entries): nothing more to stage or to send
-    const size_t total_staged = o_para + 2 * para_stride;
+    // The 64 x 64 sparse tile kernel's own lists: only phams that at least TWO genomes hold (nothing else can be shared; in real
+    // collections about half of all phams have one holder), renumbered densely in pham order, each entry as (dense id, value) pairs
+    // for one 8-byte load, plus the dense ids alone (gcs / jc) and a rank table over 64-id words of the dense space -- its mask
+    // chunks then cover the phams that matter, not the vocabulary.  Only the renumbering table is staged; the lists are made on the
+    // device (k_sp_build, one thread per genome, each genome's kept entries at the start of its own slot of the entry arrays), as
+    // are (pham, summed length) and (pham, gene count) over ALL entries in original ids for the 32 x 32 kernel (k_pair_entries).
+    int P2 = 0;
+    const size_t o_dense = (o_para + 2 * para_stride + 255) & ~(size_t)255;
+    {
+        int32_t* dense = (int32_t*)(hs + o_dense);
+        for (int p2 = 0; p2 < P; ++p2) dense[p2] = holders[(size_t)p2] >= 2u ? P2++ : -1;
+    }
+    const int W2 = std::max(1, (P2 + 63) / 64);
+    const size_t total_staged = o_dense + (((size_t)std::max(P, 1) * 4 + 255) & ~(size_t)255);
     const size_t o_pair_len = (total_staged + 255) & ~(size_t)255, o_pair_cnt = o_pair_len + 2 * ent_stride;
-    const size_t total_bytes2 = o_pair_cnt + 2 * ent_stride;
+    const size_t o_sp_end = o_pair_cnt + 2 * ent_stride, o_sp_pham = (o_sp_end + (size_t)N * 4 + 255) & ~(size_t)255, o_sp_len = o_sp_pham + ent_stride,
+                 o_sp_cnt = o_sp_len + 2 * ent_stride, o_sp_rank = o_sp_cnt + 2 * ent_stride;
+    const size_t total_bytes2 = o_sp_rank + (((size_t)N * W2 * 4 + 255) & ~(size_t)255);
     lap("entries, rank table");
     if ((rc = abi_rc(c->b_sets.ensure(total_bytes2)))) return rc;
     // (an idle GPU answers its first command after 10-25 ms, whatever the command -- DMA copy, blocking copy or a copy
@@ -493,6 +507,9 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         uint8_t* dsb = (uint8_t*)c->b_sets.p;
         if ((rc = pc_launch_pair_entries((const int32_t*)(dsb + o_ent + 3 * ent_stride), (const int32_t*)(dsb + o_ent + ent_stride), (const int32_t*)(dsb + o_ent),
                                          (uint2*)(dsb + o_pair_len), (uint2*)(dsb + o_pair_cnt), (int64_t)E, c->stream))) return rc;
+        if ((rc = pc_launch_sp_build(N, (const uint32_t*)(dsb + o_ent_off), (const int32_t*)(dsb + o_ent + 3 * ent_stride), (const int32_t*)(dsb + o_ent + ent_stride),
+                                     (const int32_t*)(dsb + o_ent), (const int32_t*)(dsb + o_dense), W2, (int32_t*)(dsb + o_sp_pham), (uint2*)(dsb + o_sp_len),
+                                     (uint2*)(dsb + o_sp_cnt), (uint32_t*)(dsb + o_sp_rank), (uint32_t*)(dsb + o_sp_end), c->stream))) return rc;
     }
     PC_HIP(hipStreamSynchronize(c->stream));
     lap("h2d sets");
@@ -507,6 +524,8 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     d.nph = (const int32_t*)(ds + o_nph); d.ngen = (const int32_t*)(ds + o_ngen); d.tlen = (const int64_t*)(ds + o_tlen);
     d.para_off = (const uint32_t*)(ds + o_para_off); d.para_pham = (const int32_t*)(ds + o_para); d.para_ex = (const int32_t*)(ds + o_para + para_stride);
     d.ent_pair_len = (const uint2*)(ds + o_pair_len); d.ent_pair_cnt = (const uint2*)(ds + o_pair_cnt);
+    d.sp_end = (const uint32_t*)(ds + o_sp_end); d.sp_pham = (const int32_t*)(ds + o_sp_pham); d.sp_len = (const uint2*)(ds + o_sp_len);
+    d.sp_cnt = (const uint2*)(ds + o_sp_cnt); d.sp_rank = (const uint32_t*)(ds + o_sp_rank); d.sp_W = W2;
     c->h_gene_len.swap(gene_len);
     c->max_gene_len = maxlen; c->min_gene_len = minlen;
     c->max_nph = 0;

@@ -24,7 +24,14 @@ struct PcDev {
     const int32_t* ent_cnt;           // [E] genes of the genome in that pham
     const int32_t* ent_len;           // [E] their summed length
     const uint2* ent_pair_len;        // [E] (pham, summed length) and
-    const uint2* ent_pair_cnt;        // [E] (pham, gene count): one 8-byte load per entry for k_sparse_tile64
+    const uint2* ent_pair_cnt;        // [E] (pham, gene count): one 8-byte load per entry for k_sparse_tile
+    // k_sparse_tile64's lists: entries of phams with at least two holders only, ids renumbered densely (sp_W 64-id words)
+    const uint32_t* sp_end;           // [N] a genome's kept entries are [ent_off[g], sp_end[g]) of the three arrays below
+    const int32_t* sp_pham;           // [E] dense id
+    const uint2* sp_len;              // [E] (dense id, summed length)
+    const uint2* sp_cnt;              // [E] (dense id, gene count)
+    const uint32_t* sp_rank;          // [N][sp_W] first kept entry of the genome at or after dense word w
+    int sp_W;
     const int32_t* ent_gene;          // [E] first gene id (genes of an entry are consecutive)
     const int32_t* ent_pham;          // [E] pham id (ascending within a genome: the set bits of its bitmap row, in order)
     const uint32_t* ent_off;          // [N+1] entries of genome g = [ent_off[g], ent_off[g+1])
@@ -98,6 +105,8 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
 int pc_launch_walk(int mode, const PcDev& d, const PcShard& sh, const PcWalkArgs& a, hipStream_t st);
 int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st);   // pocp / af
 int pc_launch_pair_entries(const int32_t* pham, const int32_t* len, const int32_t* cnt, uint2* pair_len, uint2* pair_cnt, int64_t n, hipStream_t st);
+int pc_launch_sp_build(int N, const uint32_t* ent_off, const int32_t* pham, const int32_t* len, const int32_t* cnt, const int32_t* dense, int W2,
+                       int32_t* sp_pham, uint2* sp_len, uint2* sp_cnt, uint32_t* sp_rank, uint32_t* sp_end, hipStream_t st);
 int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st); // pocp / af, large matrices
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);

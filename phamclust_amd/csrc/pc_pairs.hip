@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
     __shared__ long long tot_s[S6_T], tot_t[S6_T];                                 // its total (genes, resp. residues): the epilogue's denominators
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool COUNT = MODE >= S6_GCS;                                          // gcs / jc: |S n T| only -- every hit adds 1, and ONE direction does it
-    const uint2* __restrict__ ent = MODE == PCW_POCP ? d.ent_pair_cnt : d.ent_pair_len;      // (pham, value)
+    const uint2* __restrict__ ent = MODE == PCW_POCP ? d.sp_cnt : d.sp_len;                   // (dense pham id, value): phams with at least two holders
     // Unit n of the XCD-aware tile order goes to workgroup n mod gridDim (a multiple of 8, so a workgroup keeps to the tiles of
     // its XCD).  Tiles differ in cost by 10 x (a tile inside a cluster of related genomes shares ~85 phams per pair, one between
     // clusters ~3), so the deal must stay fine: measured at N = 20,000 with gridDim = m x the 512 resident workgroups, m = 1: 4.40 ms,
@@ -699,12 +699,12 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
         tot_t[lane] = gt_l < 0 ? 0 : (COUNT ? (long long)d.nph[gt_l] : MODE == PCW_POCP ? (long long)d.ngen[gt_l] : (long long)d.tlen[gt_l]);
     }
     for (int i = tid; i < S6_T * S6_LD; i += 64 * S6_WAVES) acc[i] = 0u;
-    for (int p0 = 0; p0 < d.Wb * 64; p0 += CH) {
-        const int w0 = p0 >> 6, w1 = min(d.Wb, (p0 + CH) >> 6);
+    for (int p0 = 0; p0 < d.sp_W * 64; p0 += CH) {
+        const int w0 = p0 >> 6, w1 = min(d.sp_W, (p0 + CH) >> 6);
         // my rows' entries of this chunk, sources and targets: ranges (wave-uniform), then 2 x 64 entries per row in registers
         uint32_t rl_s = 0, rh_s = 0, rl_t = 0, rh_t = 0;
-        if (gs_l >= 0) { rl_s = d.rankpre[(int64_t)gs_l * d.Wb + w0]; rh_s = w1 < d.Wb ? d.rankpre[(int64_t)gs_l * d.Wb + w1] : d.ent_off[gs_l + 1]; }
-        if (gt_l >= 0) { rl_t = d.rankpre[(int64_t)gt_l * d.Wb + w0]; rh_t = w1 < d.Wb ? d.rankpre[(int64_t)gt_l * d.Wb + w1] : d.ent_off[gt_l + 1]; }
+        if (gs_l >= 0) { rl_s = d.sp_rank[(int64_t)gs_l * d.sp_W + w0]; rh_s = w1 < d.sp_W ? d.sp_rank[(int64_t)gs_l * d.sp_W + w1] : d.sp_end[gs_l]; }
+        if (gt_l >= 0) { rl_t = d.sp_rank[(int64_t)gt_l * d.sp_W + w0]; rh_t = w1 < d.sp_W ? d.sp_rank[(int64_t)gt_l * d.sp_W + w1] : d.sp_end[gt_l]; }
         uint32_t lo_s[S6_RPW], hi_s[S6_RPW], lo_t[S6_RPW], hi_t[S6_RPW];
 #pragma unroll
         for (int rr = 0; rr < S6_RPW; ++rr) {
@@ -720,8 +720,8 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
                 const uint32_t es = lo_s[rr] + (uint32_t)(64 * b + lane), et = lo_t[rr] + (uint32_t)(64 * b + lane);
                 const bool is = es < hi_s[rr], it = et < hi_t[rr];
                 if constexpr (COUNT) {
-                    ph_s[rr][b] = is ? d.ent_pham[es] - p0 : -1; v_s[rr][b] = 1u;
-                    ph_t[rr][b] = it ? d.ent_pham[et] - p0 : -1; v_t[rr][b] = 1u;
+                    ph_s[rr][b] = is ? d.sp_pham[es] - p0 : -1; v_s[rr][b] = 1u;
+                    ph_t[rr][b] = it ? d.sp_pham[et] - p0 : -1; v_t[rr][b] = 1u;
                 } else {
                     const uint2 xs = is ? ent[es] : make_uint2((uint32_t)(p0 - 1), 0u), xt = it ? ent[et] : make_uint2((uint32_t)(p0 - 1), 0u);
                     ph_s[rr][b] = (int)xs.x - p0; v_s[rr][b] = xs.y;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
                 for (int b = 0; b < S6_B; ++b) if (bph[rr][b] >= 0) atomicOr(&colmask[2 * bph[rr][b] + half], bit);
                 for (uint32_t e0 = blo[rr] + 64u * S6_B; e0 < bhi[rr]; e0 += 64u) {          // rows with more entries than the registers hold
                     const uint32_t e = e0 + (uint32_t)lane;
-                    if (e < bhi[rr]) atomicOr(&colmask[2 * (d.ent_pham[e] - p0) + half], bit);
+                    if (e < bhi[rr]) atomicOr(&colmask[2 * (d.sp_pham[e] - p0) + half], bit);
                 }
             }
             __syncthreads();
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
                     const uint32_t e = e0 + (uint32_t)lane;
                     const bool in = e < qhi[rr];
                     uint2 x = make_uint2((uint32_t)(p0 - 1), 0u);
-                    if (in) { if constexpr (COUNT) x = make_uint2((uint32_t)d.ent_pham[e], 1u); else x = ent[e]; }
+                    if (in) { if constexpr (COUNT) x = make_uint2((uint32_t)d.sp_pham[e], 1u); else x = ent[e]; }
                     hit(to_row, r, (MODE == PCW_POCP && !decltype(to_row)::value && x.y <= 1u) ? -1 : (int)x.x - p0, x.y, hs);
                 }
                 if (hs) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + lane : lane * S6_LD + r], hs);
@@ -833,11 +833,38 @@ int pc_launch_pair_entries(const int32_t* pham, const int32_t* len, const int32_
     return PC_OK;
 }
 
+// A genome's entries of phams with at least two holders, dense ids, at the start of its own slot [ent_off[g], ent_off[g+1]) of the
+// sp_* arrays; sp_rank[g][w] = first of them at or after dense word w; sp_end[g] = their end.  One thread per genome (~100 entries).
+__global__ void k_sp_build(int N, const uint32_t* __restrict__ ent_off, const int32_t* __restrict__ pham, const int32_t* __restrict__ len,
+                           const int32_t* __restrict__ cnt, const int32_t* __restrict__ dense, int W2, int32_t* __restrict__ sp_pham,
+                           uint2* __restrict__ sp_len, uint2* __restrict__ sp_cnt, uint32_t* __restrict__ sp_rank, uint32_t* __restrict__ sp_end) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    uint32_t at = ent_off[g]; int w = 0;
+    uint32_t* rank = sp_rank + (int64_t)g * W2;
+    for (uint32_t e = ent_off[g]; e < ent_off[g + 1]; ++e) {
+        const int id = dense[pham[e]];
+        if (id < 0) continue;
+        for (; w <= (id >> 6); ++w) rank[w] = at;
+        sp_pham[at] = id; sp_len[at] = make_uint2((uint32_t)id, (uint32_t)len[e]); sp_cnt[at] = make_uint2((uint32_t)id, (uint32_t)cnt[e]);
+        ++at;
+    }
+    for (; w < W2; ++w) rank[w] = at;
+    sp_end[g] = at;
+}
+int pc_launch_sp_build(int N, const uint32_t* ent_off, const int32_t* pham, const int32_t* len, const int32_t* cnt, const int32_t* dense, int W2,
+                       int32_t* sp_pham, uint2* sp_len, uint2* sp_cnt, uint32_t* sp_rank, uint32_t* sp_end, hipStream_t st) {
+    if (N <= 0) return PC_OK;
+    hipLaunchKernelGGL(k_sp_build, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, N, ent_off, pham, len, cnt, dense, W2, sp_pham, sp_len, sp_cnt, sp_rank, sp_end);
+    if (hipGetLastError() != hipSuccess) { pc_set_error("k_sp_build launch failed"); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
 int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
     // mask chunk: all phams at once while two workgroups still fit a CU (8 B per pham + 17 KB of accumulators: 7,680 phams), else the
     // fewest equal chunks of at most that many
-    const int P64 = d.Wb * 64;
+    const int P64 = d.sp_W * 64;                                                    // phams with at least two holders
     // ... except that 2,048 ... 7,680 phams are split in two from ~4,000 genomes: the one-batch instances need 59 (gcs / jc), 78 (af) and --
     // held there by the launch bound, 4 dwords of scratch -- 80 (pocp) registers, and with 20 KB of masks three workgroups fit a CU instead
     // of two (N = 20,000, 5,056 phams: jc 2.06 -> 1.79 ms, af 2.89 -> 2.60, pocp 2.61 -> 2.42; below: af at N = 3,000 0.150 ms whole, 0.165 split)

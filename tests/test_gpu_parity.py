@@ -1234,6 +1234,19 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
         gpu_ctx.upload(mid, residues=False)
         for m in ("pocp", "af", "gcs", "jc"):
             assert np.array_equal(gpu_ctx.fill(m), O.fill(mid, m)), m
+        # no pham with two holders: the kernel's lists (phams that can be shared at all) are empty
+        from phamclust_amd.genome import Genome
+        from phamclust_amd.pack import pack_genomes
+        lonely = []
+        for k in range(5):
+            g = Genome(f"lonely{k}")
+            for q in range(4):
+                g.add(f"own{k}_{q}", "MKT" * (q + 1))
+            lonely.append(g)
+        lonely = pack_genomes(lonely)
+        gpu_ctx.upload(lonely, residues=False)
+        for m in ("pocp", "af", "gcs", "jc"):
+            assert np.array_equal(gpu_ctx.fill(m), O.fill(lonely, m)), m
         # an empty translation makes "sum == 0" ambiguous: the 64 x 64 kernel must step aside, whatever was asked for
         odd = _set_kernel_case(rng, 40, 300, empty_translation_in=2)
         gpu_ctx.upload(odd, residues=False)
