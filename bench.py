@@ -168,6 +168,7 @@ def main():
     import torch.distributed as dist
     from phamclust_amd import build, hip
     from phamclust_amd.distributed import dist_mode, fill_distributed, uses_alignment_slices
+    from phamclust_amd.metrics import parity_note
     from phamclust_amd.synth import synth_packed
 
     # PC_BENCH_BACKEND=gloo rehearses the N>1 flow on a box with fewer GPUs than ranks (ranks share devices, the
@@ -357,7 +358,8 @@ def main():
         got = out[torch.as_tensor(cond, device=out.device)].cpu().numpy()
         want = O.pairs(packed, a.metric, lo, hi, as_distance=True)
         line["verified"] = {"pairs": int(lo.size), "how": "random pairs of the full matrix vs oracle/pc_oracle.c",
-                            "max_abs_diff": float(np.max(np.abs(got - want))), "bit_exact": bool(np.array_equal(got, want))}
+                            "max_abs_diff": float(np.max(np.abs(got - want))), "bit_exact": bool(np.array_equal(got, want)),
+                            "parity": parity_note(a.metric)}
     if world == 1:
         # SURVEY 8(d)'s wall time of one matrix: upload + kernels + D2H of the condensed vector (host clock, second of two)
         for _ in range(2):

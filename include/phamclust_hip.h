@@ -86,6 +86,9 @@ typedef struct {
 
 int pc_version(void);
 const char* pc_last_error(void);
+/* 1 in a library compiled with -DPC_TEST_HOOKS (libphamclust_hip_hooks.so: fault injection for the tests, see the knob table
+ * at the end of this header), 0 in the release library. */
+int pc_test_hooks(void);
 
 /* One context per GPU.  device_id is the HIP device ordinal. */
 int pc_ctx_create(pc_ctx** out, int device_id);

@@ -161,11 +161,13 @@ def _struct(packed):
 
 
 def pair(packed, metric, s, t, as_distance=True):
+    _require_default_switches("pair")
     return lib().pco_pair(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), s, t)
 
 
 def pairs(packed, metric, s_idx, t_idx, as_distance=True, nthreads=0):
     """Values of the listed pairs (s < t required, as in the matrix's upper triangle)."""
+    _require_default_switches("pairs")
     s_idx = np.ascontiguousarray(s_idx, dtype=np.int32)
     t_idx = np.ascontiguousarray(t_idx, dtype=np.int32)
     assert (s_idx < t_idx).all()
@@ -177,6 +179,7 @@ def pairs(packed, metric, s_idx, t_idx, as_distance=True, nthreads=0):
 
 def fill(packed, metric, as_distance=True, nthreads=0):
     """Condensed (scipy order) f64 vector of the N(N-1)/2 pair values."""
+    _require_default_switches("fill")
     out = np.zeros(packed.n_genomes * (packed.n_genomes - 1) // 2, dtype=np.float64)
     rc = lib().pco_fill(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), _ptr(out, _f64p), nthreads)
     if rc != 0:
@@ -186,6 +189,7 @@ def fill(packed, metric, as_distance=True, nthreads=0):
 
 def fill_rows(packed, metric, row_begin, row_end, as_distance=True, nthreads=0):
     """Rows [row_begin,row_end) only (bounded CPU-baseline sample).  Returns (condensed, n_aln, n_cells)."""
+    _require_default_switches("fill_rows")
     out = np.zeros(packed.n_genomes * (packed.n_genomes - 1) // 2, dtype=np.float64)
     stats = np.zeros(2, dtype=np.int64)
     rc = lib().pco_fill_rows(ctypes.byref(_struct(packed)), METRIC_IDS[metric], int(as_distance), row_begin, row_end,
@@ -291,14 +295,57 @@ def enumerate_alignments(packed, s_idx, t_idx):
     return a, b, q
 
 
+_DEFAULT_SWITCHES = {"gap": (11, 1), "compat": (False, 23, False)}
+_switches = dict(_DEFAULT_SWITCHES)       # what the C library was last told (its switches are process-global)
+_scoped = 0                               # > 0 inside `with gap(...)` / `with compat(...)`: non-default on purpose
+
+
 def set_gap(open_=11, extend=1):
-    """Gap costs of every aligner entry point (process-wide); the reference's are 11 / 1 (metrics.py:160)."""
+    """Gap costs of every aligner entry point (process-wide); the reference's are 11 / 1 (metrics.py:160).  Prefer
+    ``with gap(12, 1): ...``, which restores the default; a bare call leaves the checker switched for the rest of the process,
+    and ``fill`` / ``pairs`` / ``pair`` / ``fill_rows`` then refuse to answer (see ``_require_default_switches``)."""
     lib().pco_set_gap(int(open_), int(extend))
+    _switches["gap"] = (int(open_), int(extend))
 
 
 def set_compat(case_sensitive=False, unknown_row=23, lower_unknown=False):
-    """Recalled parasail behaviours as switches; defaults restore them."""
+    """Recalled parasail behaviours as switches; defaults restore them.  Prefer ``with compat(...)``."""
     lib().pco_set_compat(int(bool(case_sensitive)), int(unknown_row), int(bool(lower_unknown)))
+    _switches["compat"] = (bool(case_sensitive), int(unknown_row), bool(lower_unknown))
+
+
+class _scoped_switch:
+    def __init__(self, setter, args, kwargs):
+        self._setter, self._args, self._kwargs = setter, args, kwargs
+
+    def __enter__(self):
+        global _scoped
+        _scoped += 1
+        self._setter(*self._args, **self._kwargs)
+
+    def __exit__(self, *exc):
+        global _scoped
+        self._setter()                                        # the defaults
+        _scoped -= 1
+
+
+def gap(open_=11, extend=1):
+    """``with gap(12, 1): ...`` -- the other affine convention for the block, 11 / 1 again afterwards."""
+    return _scoped_switch(set_gap, (open_, extend), {})
+
+
+def compat(**kwargs):
+    """``with compat(case_sensitive=True): ...`` -- one recalled convention flipped for the block, defaults afterwards."""
+    return _scoped_switch(set_compat, (), kwargs)
+
+
+def _require_default_switches(what):
+    """The matrix entry points are what the GPU path is compared with: they answer only with the reference's conventions in
+    force (a stray set_gap / set_compat would silently turn every later comparison of the process into one against
+    another aligner), unless the caller is inside one of the context managers above."""
+    if _scoped == 0 and _switches != _DEFAULT_SWITCHES:
+        raise RuntimeError(f"oracle.{what}: the checker's conventions were left switched ({_switches}); "
+                           f"call set_gap() / set_compat() to restore the defaults, or use `with gap(...)` / `with compat(...)`")
 
 
 # ---------------------------------------------------------------------------

@@ -23,8 +23,12 @@ HIP_UNITS = [("pc_api.hip", "pc_api.o", []), ("pc_pairs.hip", "pc_pairs.o", []),
              ("pc_nw_rules.hip", "pc_nw_r23.o", ["-DPC_RULE_A=2", "-DPC_RULE_B=3"]),
              ("pc_nw_rules.hip", "pc_nw_r45.o", ["-DPC_RULE_A=4", "-DPC_RULE_B=5"]),
              ("pc_nw_rules.hip", "pc_nw_r67.o", ["-DPC_RULE_A=6", "-DPC_RULE_B=7"])]
+# the same library once more with pc_api.hip compiled under -DPC_TEST_HOOKS (fault injection: PC_FAKE_OOM_ABOVE); every other
+# object is shared.  Loaded only by the test that needs it (PHAMCLUST_NATIVE_VARIANT=hooks).
+HOOKS_UNIT = ("pc_api.hip", "pc_api_hooks.o", ["-DPC_TEST_HOOKS"])
 HIP_SOURCES = sorted({u[0] for u in HIP_UNITS})
 HIP_LIB = os.path.join(CSRC, "libphamclust_hip.so")
+HIP_HOOKS_LIB = os.path.join(CSRC, "libphamclust_hip_hooks.so")
 SYNTH_LIB = os.path.join(CSRC, "libpc_synth.so")
 PACK_LIB = os.path.join(CSRC, "libpc_pack.so")
 # Every unit is compiled with -cuid=<its object's name>: hipcc otherwise derives the compilation-unit id from the source file's
@@ -46,7 +50,7 @@ def build_hip(force=False, verbose=False):
     headers = [os.path.join(CSRC, "pc_common.h"), os.path.join(CSRC, "pc_nw_systolic.h"),
                os.path.join(CSRC, "..", "..", "include", "phamclust_hip.h")]
     objs, jobs = [], []
-    for src, obj_name, extra in HIP_UNITS:
+    for src, obj_name, extra in HIP_UNITS + [HOOKS_UNIT]:
         src_path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, obj_name)
         if force or _stale(obj, [src_path] + headers):
@@ -58,11 +62,13 @@ def build_hip(force=False, verbose=False):
     failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    if force or _stale(HIP_LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    hooks_obj = objs.pop()
+    for lib, lib_objs in ((HIP_LIB, objs), (HIP_HOOKS_LIB, [hooks_obj] + objs[1:])):
+        if force or _stale(lib, lib_objs):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + lib_objs + ["-ldl"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return HIP_LIB
 
 

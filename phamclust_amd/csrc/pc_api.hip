@@ -12,6 +12,7 @@
 // many row sequences through it; results are written pair-major so step 6 reads them
 // contiguously and in the canonical order (pham id, anchor gene, other gene).
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -60,19 +61,32 @@ void pc_set_error(const char* fmt, ...) {
 }
 extern "C" const char* pc_last_error(void) { return g_err; }
 extern "C" int pc_version(void) { return PC_VERSION; }
+extern "C" int pc_test_hooks(void) {
+#ifdef PC_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 namespace {
 
 // internal status: a device allocation failed.  A chunked fill answers it with smaller chunks; at the C-ABI it is PC_ERR_HIP.
 constexpr int PC_ERR_NOMEM_INTERNAL = -100;
-// test hook (PC_FAKE_OOM_ABOVE=bytes): device allocations above that size made while a fill is planning fail, as if HBM
-// were that small
+// Fault injection (PC_FAKE_OOM_ABOVE=bytes): device allocations above that size made while a fill is planning fail, as if HBM
+// were that small.  Compiled only under -DPC_TEST_HOOKS, i.e. into libphamclust_hip_hooks.so, the twin that
+// test_out_of_memory_plan_becomes_smaller_chunks loads; the release library has no such switch (pc_test_hooks() tells which is which).
+#ifdef PC_TEST_HOOKS
 static thread_local bool g_planning = false;
 static size_t fake_oom_limit() {
     static const size_t v = [] { const char* e = getenv("PC_FAKE_OOM_ABOVE"); return e ? (size_t)atoll(e) : (size_t)0; }();
     return g_planning ? v : 0;
 }
 struct PlanningScope { PlanningScope() { g_planning = true; } ~PlanningScope() { g_planning = false; } };
+#else
+static constexpr size_t fake_oom_limit() { return 0; }
+struct PlanningScope { PlanningScope() {} };
+#endif
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int ensure(size_t bytes) {
@@ -120,6 +134,7 @@ template <class T> int upload_vec(DevBuf& b, const std::vector<T>& v) {
 
 struct pc_ctx {
     int device = 0;
+    int n_cu = 256;                         // compute units of THIS context's device (grid sizing of the persistent tile kernels)
     hipStream_t stream = nullptr;
     bool uploaded = false;                  // part 1 of the upload is on the device (set metrics can run)
     bool residues_ready = false;            // ... and part 2 (aai / peq, pc_align_pairs can run)
@@ -131,8 +146,9 @@ struct pc_ctx {
     int64_t max_tlen = 0;                    // largest summed translation length of a genome
     double avg_shared = 0.0;                 // phams an average genome pair shares (pocp's kernel choice)
     // kernel-variant classes over column genes
-    int ncls_all = 0;                       // launch classes: variant * 4 + lanes-per-segment bucket, last = general kernel
-    std::vector<int32_t> cls_max_lb;        // [ncls_all] longest column sequence that can land in the class (LDS size of its launch)
+    int ncls_all = 0;                       // BASE classes: variant * 4 + lanes-per-segment bucket (twice: "any byte" columns), last = general kernel
+    int nlc = 0;                            // launch classes = ncls_all * PC_WAVE_MODES (base class x workgroup shape of the task, pc_common.h)
+    std::vector<int32_t> cls_max_lb;        // [nlc] longest column sequence that can land in the launch class (LDS size of its launch)
     PcTaskPlan task_plan{};
     // shard
     int rank = 0, world = 1;
@@ -166,10 +182,10 @@ struct pc_ctx {
     double* h_out = nullptr; size_t h_out_cap = 0;   // pinned result buffer lent out by pc_fill_borrow (grow-only)
     float last_align_ms = 0.f;              // kernel time of the last pc_align_pairs call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    static constexpr int kAux = 7;          // + the caller's stream = 8 concurrent alignment launches
+    static constexpr int kAux = 15;         // + the caller's stream = up to 16 concurrent alignment launches (8 by default)
     hipStream_t aux[kAux] = {};             // alignment launches of different classes overlap on these
     hipEvent_t aux_ev[kAux + 1] = {};
-    int n_streams = kAux + 1;               // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
+    int n_streams = 8;                      // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
     int tie_rule = 0;                       // row of the aligner's tie-rule table (pc_set_tie_rule)
     int64_t lut_key = -1; const double* lut_ptr = nullptr;   // what the gcs / jc epilogue table in b_lut was built for
     hipEvent_t ev_last = nullptr;           // recorded at the end of every entry point that leaves work on a caller's stream
@@ -225,6 +241,7 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     pc_ctx* c = new (std::nothrow) pc_ctx();
     if (!c) { pc_set_error("out of host memory"); return PC_ERR_ARG; }
     c->device = device_id;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cu = cus; }
     PcDeviceGuard guard(device_id);
     hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -381,16 +398,16 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     std::vector<int32_t> gene_len(G);
     std::vector<int> bad(N, 0);                          // per genome: 0 ok, else the error class found by the worker
     {   // gene lengths
-        std::vector<int> over(1, -1);
+        std::atomic<int> over(-1);                                   // one offender to report: any will do
         parallel_chunks(G, [&](int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; ++k) {
                 const int64_t len = g->seq_off[k + 1] - g->seq_off[k];
-                if (len < 0 || len > 65535) { over[0] = (int)k; gene_len[k] = 0; } else gene_len[k] = (int32_t)len;   // (racy write of ONE reported index: any offender will do)
+                if (len < 0 || len > 65535) { over.store((int)k, std::memory_order_relaxed); gene_len[k] = 0; } else gene_len[k] = (int32_t)len;
                 gene_len_h[k] = gene_len[k];
             }
         }, 65536);                                                   // (a thread costs ~30 us to start: few of them for small inputs)
-        if (over[0] >= 0) {
-            const int k = over[0];
+        if (over.load() >= 0) {
+            const int k = over.load();
             pc_set_error("pc_upload: gene %d has length %lld (limit 65535)", k, (long long)(g->seq_off[k + 1] - g->seq_off[k])); return PC_ERR_LIMIT;
         }
     }
@@ -412,13 +429,18 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
             ent_off[(size_t)s + 1] = (uint32_t)bits;
         }
     }, 1024);
-    for (int s = 0; s < N; ++s) ent_off[(size_t)s + 1] += ent_off[s];
+    {   // prefix sum in 64 bits, refused as soon as it passes the gene count (a malformed bitmap must not wrap the 32-bit offsets)
+        uint64_t run = 0;
+        for (int s = 0; s < N; ++s) {
+            run += ent_off[(size_t)s + 1];
+            if (run > (uint64_t)G) { pc_set_error("pc_upload: the bitmap holds more phams than there are genes"); return PC_ERR_ARG; }
+            ent_off[(size_t)s + 1] = (uint32_t)run;
+        }
+    }
     const size_t E = ent_off[N];
-    if (E > (size_t)G) { pc_set_error("pc_upload: the bitmap holds more phams than there are genes"); return PC_ERR_ARG; }
     const size_t ent_stride = ((size_t)std::max<size_t>(E, 1) * 4 + 255) & ~(size_t)255;
     int32_t* ent_cnt = (int32_t*)(hs + o_ent); int32_t* ent_len = (int32_t*)(hs + o_ent + ent_stride);
     int32_t* ent_gene = (int32_t*)(hs + o_ent + 2 * ent_stride); int32_t* ent_pham = (int32_t*)(hs + o_ent + 3 * ent_stride);
-    const size_t total_bytes = o_ent + 4 * ent_stride;
     // pass 2: a genome's entries, its rank table, and the consistency checks
     parallel_chunks(N, [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s) {
@@ -516,7 +538,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     uint8_t* ds = (uint8_t*)c->b_sets.p;
     PcDev& d = c->dev;
     memset(&d, 0, sizeof(d));
-    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)E;
+    d.N = N; d.Wb = W; d.Wstride = Wstride; d.G = G; d.E = (int64_t)E; d.n_cu = c->n_cu;
     d.bitmap = (const uint64_t*)(ds + o_bitmap); d.rankpre = (const uint32_t*)(ds + o_rankpre);
     d.ent_cnt = (const int32_t*)(ds + o_ent); d.ent_len = (const int32_t*)(ds + o_ent + ent_stride);
     d.ent_gene = (const int32_t*)(ds + o_ent + 2 * ent_stride); d.ent_pham = (const int32_t*)(ds + o_ent + 3 * ent_stride);
@@ -673,7 +695,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
         u_cls[u] = godd[u_gene[u]] ? pc_class_of(len, len_var[len], true) : len_cls[len]; ++cls_count[u_cls[u]];
     }
     lap("  classes per sequence");
-    if (ncls_all > 250) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // class ids travel in a byte, 255 = none
+    if (ncls_all > 250 || ncls_all * PC_WAVE_MODES + 1 > 1000) { pc_set_error("too many kernel classes"); return PC_ERR_LIMIT; }   // base class ids travel in a byte, 255 = none; the plan read-back holds 1,000 words
     c->ncls_all = ncls_all;
     std::vector<int64_t> cls_pos(ncls_all, 0);
     { int64_t run = 0; for (int cls = 0; cls < ncls_all; ++cls) { cls_pos[cls] = run; run += cls_count[cls]; } }
@@ -789,16 +811,28 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
         PcLut lut_arg;
         memcpy(lut_arg.v, lut, 256);
         if ((!staged && (rc = upload_raw(c->b_raw, raw + g->seq_off[0], (size_t)raw_bytes))) || (rc = abi_rc(c->b_codes.ensure(codes_size))) ||
-            (rc = abi_rc(c->b_cls_begin.ensure((ncls_all + 1) * 4)))) return rc;
+            (rc = abi_rc(c->b_cls_begin.ensure(((size_t)ncls_all * PC_WAVE_MODES + 1) * 4)))) return rc;
         if (code_bytes < 16) PC_HIP(hipMemsetAsync(c->b_codes.p, PC_PADCODE, 16, c->stream));
         rc = pc_launch_encode(c->b_raw.as<uint8_t>(), c->b_seq_tmp.as<int64_t>(), c->b_gene_off.as<int64_t>(), c->dev.gene_len, lut_arg,
                               c->b_codes.as<uint8_t>(), G, c->stream);
         hipError_t e = hipStreamSynchronize(c->stream);
         if (rc != PC_OK) return rc;
         if (e != hipSuccess) { pc_set_error("pc_upload: residue tables / encoding: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+        // The raw bytes and their offsets were staging for k_encode only.  Kept (grow-only) they would double the residue footprint
+        // for the life of the context and shrink what plan_budget_bytes() sees as free -- more chunks for exactly the collections
+        // that are chunked; small ones keep them, so that repeated uploads do not pay a hipMalloc each (threshold 256 MB).
+        if (c->b_raw.cap + c->b_seq_tmp.cap > ((size_t)256 << 20)) { c->b_raw.release(); c->b_seq_tmp.release(); }
     }
     c->task_plan.task_rows = c->b_task_rows.as<int32_t>(); c->task_plan.q_class = c->b_q_class.as<uint8_t>();
     c->task_plan.q_nseg = c->b_q_nseg.as<uint8_t>(); c->task_plan.rem_class = c->b_rem_class.as<uint8_t>();
+    c->task_plan.nvar = pc_nw_num_variants(); c->task_plan.small_modes = pc_nw_small_modes_enabled();
+    for (int v = 0; v < 32; ++v) c->task_plan.variant_w[v] = v < pc_nw_num_variants() ? pc_nw_variant_w(v) : 0;
+    {   // launch classes: every base class in its three workgroup shapes, each with the base class's longest column gene
+        std::vector<int32_t> per_base; per_base.swap(c->cls_max_lb);
+        c->nlc = ncls_all * PC_WAVE_MODES;
+        c->cls_max_lb.resize((size_t)c->nlc);
+        for (int lc = 0; lc < c->nlc; ++lc) c->cls_max_lb[(size_t)lc] = per_base[(size_t)(lc / PC_WAVE_MODES)];
+    }
     PcDev& d = c->dev;
     d.U = U; d.ubits = ubits; d.gene_q = c->b_gene_q.as<uint32_t>(); d.q_gene = c->b_q_gene.as<int32_t>();
     d.gene_off = c->b_gene_off.as<int64_t>(); d.codes = c->b_codes.as<uint8_t>();
@@ -912,53 +946,71 @@ extern "C" int pc_target_costs(const pc_ctx* c, uint64_t* cost) {
 extern "C" int64_t pc_shard_pairs(const pc_ctx* c) { return c && c->uploaded ? c->shard_pairs : -1; }
 extern "C" int64_t pc_shard_stride(const pc_ctx* c) { return c && c->uploaded ? c->shard_stride : -1; }
 
-// Steps 5 of the plan: launch the alignment kernels for every class that has tasks.
-// Step 5 of the plan: launch the alignment kernels for every class that has tasks.  Classes are
+// Step 5 of the plan: launch the alignment kernels for every launch class that has tasks.  Classes are
 // independent (disjoint result slots), so their launches are spread over the caller's stream and
 // seven auxiliary streams: the drain of one class overlaps the next one's start.
-static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[ncls_all+1]*/, const int32_t* cls_max_lb,
+static int small_launch_min() {              // fewest tasks that earn a one- / two-wave mode a launch of its own
+    static const int v = [] { const char* e = getenv("PC_SMALL_LAUNCH_MIN"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
+    return v;
+}
+static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t* task_begin /*[nlc+1]*/, const int32_t* cls_max_lb,
                              uint2* res, hipStream_t st, pc_stats* stats, int ppos) {
-    const int ncls = c->ncls_all;
-    auto variant_of = [&](int cls) { return pc_class_variant(cls); };
-    std::vector<int> order;
-    for (int i = 0; i < ncls; ++i) if (task_begin[i + 1] > task_begin[i]) order.push_back(i);
+    const int nbase = c->ncls_all;
+    // One launch = a run of neighbouring launch classes of ONE base class, run in the workgroup shape of the first of them.  The
+    // modes of a base class follow each other in the sorted task list (own shape, two waves, one wave), so a small-task mode with
+    // too few tasks to pay for a launch of its own -- every launch holds its hardware queue until its last workgroup is done --
+    // rides at the end of the launch before it: correct in any shape, merely less snug.
+    struct Launch { uint32_t begin, end; int base, mode, max_lb; };
+    std::vector<Launch> launches;
+    for (int b = 0; b < nbase; ++b) {
+        const uint32_t* tb = task_begin + (size_t)b * PC_WAVE_MODES;
+        if (tb[PC_WAVE_MODES] == tb[0]) continue;
+        const uint32_t n0 = tb[1] - tb[0], n1 = tb[2] - tb[1], n2 = tb[3] - tb[2];
+        const uint32_t least = (uint32_t)small_launch_min();
+        const bool own2 = n2 >= least, own1 = n1 + (own2 ? 0u : n2) >= least;      // one-wave tasks alone? two-wave (+ folded one-wave) alone?
+        uint32_t at = tb[0];
+        const int max_lb = cls_max_lb[b * PC_WAVE_MODES];
+        auto put = [&](uint32_t n, int mode) { if (n) launches.push_back({at, at + n, b, mode, max_lb}); at += n; };
+        if (own1) { put(n0, PC_MODE_CLASS); put(n1 + (own2 ? 0u : n2), n1 ? PC_MODE_TWO_WAVES : PC_MODE_ONE_WAVE); }
+        else put(n0 + n1 + (own2 ? 0u : n2), n0 ? PC_MODE_CLASS : n1 ? PC_MODE_TWO_WAVES : PC_MODE_ONE_WAVE);
+        if (own2) put(n2, PC_MODE_ONE_WAVE);
+    }
+    if (launches.empty()) return PC_OK;
     // longest tasks first (a task's duration grows with its column gene's length): the tail of the fill is then made
     // of short tasks.  PC_ALIGN_ORDER=size restores largest-class-first for A/B runs
     static const bool by_size = getenv("PC_ALIGN_ORDER") && !strcmp(getenv("PC_ALIGN_ORDER"), "size");
-    std::sort(order.begin(), order.end(), [&](int x, int y) {
-        if (by_size) {
-            const uint32_t nx = task_begin[x + 1] - task_begin[x], ny = task_begin[y + 1] - task_begin[y];
-            return nx != ny ? nx > ny : x < y;
-        }
-        return cls_max_lb[x] != cls_max_lb[y] ? cls_max_lb[x] > cls_max_lb[y] : x < y;
+    std::stable_sort(launches.begin(), launches.end(), [&](const Launch& x, const Launch& y) {
+        if (by_size) return x.end - x.begin > y.end - y.begin;
+        if (x.max_lb != y.max_lb) return x.max_lb > y.max_lb;
+        return x.base != y.base ? x.base < y.base : x.mode < y.mode;
     });
-    if (order.empty()) return PC_OK;
     // scratch of the general kernel: sized once for the longest column gene that will use it (never re-allocated
     // between launches)
     size_t sbytes = 0;
     // percent-positives: systolic where the profile cell can run (it reads "positive" from a table), general kernel elsewhere
-    auto launch_variant = [&](int i) { const int v = variant_of(i); return (ppos && !pc_nw_ppos_systolic(v, cls_max_lb[i])) ? pc_nw_ppos_variant(cls_max_lb[i]) : v; };
-    for (int i : order) if (launch_variant(i) < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(cls_max_lb[i]));
+    auto launch_variant = [&](const Launch& l) { const int v = pc_class_variant(l.base); return (ppos && !pc_nw_ppos_systolic(v, l.max_lb)) ? pc_nw_ppos_variant(l.max_lb) : v; };
+    for (const Launch& l : launches) if (launch_variant(l) < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(l.max_lb));
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     constexpr int kAux = pc_ctx::kAux;
+    const int n_aux = std::min((int)launches.size(), c->n_streams) - 1;      // auxiliary streams this fill uses
     PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
-    for (int k = 0; k < kAux; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[kAux], 0));
+    for (int k = 0; k < n_aux; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[kAux], 0));
     int slot = 0, first_error = PC_OK;
-    for (int i : order) {
-        const int nt = (int)(task_begin[i + 1] - task_begin[i]);
-        const int variant = launch_variant(i);
+    for (const Launch& l : launches) {
+        const int nt = (int)(l.end - l.begin);
+        const int variant = launch_variant(l);
         // launches that use the one scratch slab stay in order on the caller's stream
         hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
-        int rc = pc_launch_nw(variant, c->dev, task_list + task_begin[i], nt, c->b_bucket_row.as<int32_t>(),
+        int rc = pc_launch_nw(variant, c->dev, task_list + l.begin, nt, c->b_bucket_row.as<int32_t>(),
                               nullptr /* result slot = position in the sorted list */, res, variant < 0 ? c->b_scratch.p : nullptr,
-                              variant < 0 ? c->b_scratch.cap : 0, cls_max_lb[i], ppos, c->tie_rule, pc_class_compare_only(i), ls);
+                              variant < 0 ? c->b_scratch.cap : 0, l.max_lb, ppos, c->tie_rule, pc_class_compare_only(l.base), ls, l.mode);
         if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
-        slot = (slot + 1) % c->n_streams;
+        slot = (slot + 1) % (n_aux + 1);
     }
     // join the auxiliary streams back into the caller's stream -- also after a failed launch, so that what was
     // already queued on them is ordered before anything the caller does next
-    for (int k = 0; k < kAux; ++k) {
+    for (int k = 0; k < n_aux; ++k) {
         PC_HIP(hipEventRecord(c->aux_ev[k], c->aux[k]));
         PC_HIP(hipStreamWaitEvent(st, c->aux_ev[k], 0));
     }
@@ -1063,7 +1115,7 @@ static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st, int k0
     PlanningScope planning;
     const PcDev& d = c->dev;
     pc_ctx::PlanState& P = c->plan;
-    P.valid = false; P.ppos = ppos; P.condensed = condensed; P.A = (int64_t)A; P.n_distinct = 0; P.ntasks = 0; P.tb.assign(c->ncls_all + 1, 0);
+    P.valid = false; P.ppos = ppos; P.condensed = condensed; P.A = (int64_t)A; P.n_distinct = 0; P.ntasks = 0; P.tb.assign(c->nlc + 1, 0);
     P.k0 = k0; P.k1 = k1; P.whole = c->world == 1 && condensed == 1 && k0 == 0 && k1 == c->shard.nown;
     memset(&P.st, 0, sizeof(P.st));
     pc_stats& local = P.st;
@@ -1074,7 +1126,7 @@ static int stage_plan(pc_ctx* c, int ppos, int condensed, hipStream_t st, int k0
         pc_set_error("plan: %llu alignments behind ONE target genome exceed the 2^31-2 a plan can index", (unsigned long long)A); return PC_ERR_LIMIT;
     }
     const int U = d.U;
-    const int ncls = c->ncls_all;
+    const int ncls = c->nlc;
     const int64_t tmp_fixed = std::max<int64_t>(Lc + 1, U + 1);
     if ((rc = c->b_start_q.ensure((U + 1) * 4)) || (rc = c->b_end_q.ensure((U + 1) * 4)) || (rc = c->b_ntask_q.ensure((U + 1) * 4)) ||
         (rc = c->b_task_off_q.ensure((U + 1) * 4)) || (rc = c->b_scan_tmp.ensure(pc_scan_tmp_elems(tmp_fixed) * 4)) || (rc = c->b_plan.ensure(4096)))
@@ -1154,7 +1206,7 @@ static int stage_align(pc_ctx* c, int slice_rank, int slice_world, uint2* res, h
     if (!P.valid) { pc_set_error("align: no plan (pc_plan_dev first)"); return PC_ERR_STATE; }
     if (P.A <= 0 || P.ntasks == 0) return PC_OK;
     int rc = PC_OK;
-    const int ncls = c->ncls_all;
+    const int ncls = c->nlc;
     const PcTask* task_list = c->b_tasks_sorted.as<PcTask>();
     std::vector<uint32_t> tb = P.tb;
     if (slice_world > 1) {
@@ -1329,16 +1381,16 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         // only, so it is rebuilt only when one of them changes.
         const int top = metric == PC_POCP ? c->max_ngen : c->max_nph;
         const int sh_dim = metric == PC_POCP ? 2 * top + 1 : top + 1, tot_dim = 2 * top + 1;
-        double* lut = nullptr; bool build_lut = false;
+        double* lut = nullptr; bool build_lut = false; int64_t lut_key_now = -1;
         if ((int64_t)sh_dim * tot_dim <= (4 << 20)) {
             if ((rc = c->b_lut.ensure((size_t)sh_dim * tot_dim * 8))) return rc == PC_ERR_NOMEM_INTERNAL ? PC_ERR_HIP : rc;
             lut = c->b_lut.as<double>();
-            const int64_t key = ((int64_t)metric << 40) | ((int64_t)as_distance << 32) | (int64_t)top;
-            build_lut = key != c->lut_key || lut != c->lut_ptr;
-            c->lut_key = key; c->lut_ptr = lut;
+            lut_key_now = ((int64_t)metric << 40) | ((int64_t)as_distance << 32) | (int64_t)top;
+            build_lut = lut_key_now != c->lut_key || lut != c->lut_ptr;
         }
         rc = pc_launch_set_popc(d, c->shard, metric, as_distance, out, condensed, lut, build_lut, sh_dim, tot_dim, st);
-        if (rc != PC_OK) return rc;
+        if (rc != PC_OK) { c->lut_key = -1; c->lut_ptr = nullptr; return rc; }           // (whatever the table holds now, it is not trusted)
+        if (lut) { c->lut_key = lut_key_now; c->lut_ptr = lut; }                          // remembered only once its build was launched
         PC_HIP(hipEventRecord(c->ev[3], st));
         local.n_chunks = 1;
     } else if (metric == PC_POCP || metric == PC_AF) {
@@ -1556,34 +1608,49 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         return x < y;
     });
     std::vector<int32_t> rows(n); std::vector<uint32_t> dest(n); std::vector<PcTask> tasks;
-    const int ncls_all = pc_num_classes();
-    std::vector<uint32_t> cls_task_begin(ncls_all + 1, 0);
-    std::vector<int> cls_maxlb(ncls_all, 0);
+    const int nlc = pc_num_classes() * PC_WAVE_MODES;
+    std::vector<uint32_t> cls_task_begin(nlc + 1, 0);
+    std::vector<int> cls_maxlb(nlc, 0);
     {
-        int cur_cls = -1;
+        // Buckets (runs of one column gene) are cut the way the fill's planner cuts them (pc_plan.hip): tasks of the class's row
+        // count; with the automatic variant also the left-over rows of a wave round to the remainder chooser's variant, and every
+        // task in the launch mode its row count asks for.  A forced variant keeps its class's own workgroup shape.
         for (int64_t i = 0; i < n;) {
             const int64_t k = order[i];
-            while (cur_cls < cls[k]) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
             int64_t j = i;
             while (j < n && cls[order[j]] == cls[k] && b_gene[order[j]] == b_gene[k]) ++j;
-            const int per = pc_nw_task_rows(c->h_gene_len[b_gene[k]], pc_class_variant(cls[k]), pc_class_compare_only(cls[k]));
-            for (int64_t r = i; r < j; r += per) {
-                PcTask t; t.gene = b_gene[k]; t.begin = (int32_t)r; t.end = (int32_t)std::min<int64_t>(j, r + per); t.pad = 0;
-                tasks.push_back(t);
+            const int lb = c->h_gene_len[b_gene[k]], v = pc_class_variant(cls[k]);
+            const bool odd = c->h_gene_odd[b_gene[k]] != 0;
+            const int per = pc_nw_task_rows(lb, v, pc_class_compare_only(cls[k]));
+            int64_t jmain = j; int rem_cls = -1;
+            if (forced == -2 && v >= 0) {
+                const int W = pc_nw_variant_w(v), G = (lb + W - 1) / W, nseg = std::min(G > 64 ? 1 : 64 / G, 16);
+                const int r = nseg > 1 ? (int)((j - i) % nseg) : 0;
+                const int vr = r ? pc_nw_choose_remainder(lb, r, v) : -1;
+                if (vr >= 0) { jmain = j - r; rem_cls = pc_class_of(lb, vr, odd); }
             }
-            cls_maxlb[cls[k]] = std::max(cls_maxlb[cls[k]], (int)c->h_gene_len[b_gene[k]]);
+            auto put = [&](int64_t r0, int64_t r1, int base) {
+                PcTask t; t.gene = b_gene[k]; t.begin = (int32_t)r0; t.end = (int32_t)r1;
+                const int mode = forced == -2 ? pc_nw_task_mode(lb, (int)(r1 - r0), pc_class_variant(base)) : PC_MODE_CLASS;
+                t.pad = base * PC_WAVE_MODES + mode;
+                cls_maxlb[t.pad] = std::max(cls_maxlb[t.pad], lb);
+                tasks.push_back(t);
+            };
+            for (int64_t r = i; r < jmain; r += per) put(r, std::min<int64_t>(jmain, r + per), cls[k]);
+            if (rem_cls >= 0) put(jmain, j, rem_cls);
             for (int64_t r = i; r < j; ++r) { rows[r] = a_gene[order[r]]; dest[r] = (uint32_t)order[r]; }
             i = j;
         }
-        while (cur_cls < ncls_all) { ++cur_cls; cls_task_begin[cur_cls] = (uint32_t)tasks.size(); }
-        // Longest tasks first inside a class, as pc_fill's plan orders them.  Workgroups go to the 8 XCDs round-robin by block
-        // index, so a list that alternates full tasks and left-overs (every bucket cut the same way) puts all the full ones on
-        // half of the XCDs: measured 2x the time on uniform test data.
-        for (int cl = 0; cl < ncls_all; ++cl)
-            std::stable_sort(tasks.begin() + cls_task_begin[cl], tasks.begin() + cls_task_begin[cl + 1], [&](const PcTask& x, const PcTask& y) {
-                const int64_t wx = (int64_t)(x.end - x.begin) * c->h_gene_len[x.gene], wy = (int64_t)(y.end - y.begin) * c->h_gene_len[y.gene];
-                return wx > wy;
-            });
+        // By launch class, longest tasks first inside a class, as pc_fill's plan orders them.  Workgroups go to the 8 XCDs
+        // round-robin by block index, so a list that alternates full tasks and left-overs (every bucket cut the same way) puts
+        // all the full ones on half of the XCDs: measured 2x the time on uniform test data.
+        std::stable_sort(tasks.begin(), tasks.end(), [&](const PcTask& x, const PcTask& y) {
+            if (x.pad != y.pad) return x.pad < y.pad;
+            const int64_t wx = (int64_t)(x.end - x.begin) * c->h_gene_len[x.gene], wy = (int64_t)(y.end - y.begin) * c->h_gene_len[y.gene];
+            return wx > wy;
+        });
+        size_t at = 0;
+        for (int lc = 0; lc <= nlc; ++lc) { while (at < tasks.size() && tasks[at].pad < lc) ++at; cls_task_begin[lc] = (uint32_t)at; }
     }
     DevBuf d_sums, d_ident, d_diag;
     hipStream_t st = c->stream;
@@ -1591,18 +1658,19 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
     if ((rc = upload_vec(c->b_bucket_row, rows)) || (rc = upload_vec(c->b_bucket_dest, dest)) || (rc = upload_vec(c->b_tasks, tasks)) ||
         (rc = c->b_res.ensure(n * 8)) || (rc = upload_vec(d_sums, sums)) || (rc = d_ident.ensure(n * 4)) || (rc = d_diag.ensure(n * 4))) { cleanup(); return abi_rc(rc); }
     (void)hipEventRecord(c->ev[1], st);
-    for (int cl = 0; cl < ncls_all; ++cl) {
-        const int nt = (int)(cls_task_begin[cl + 1] - cls_task_begin[cl]);
+    for (int lc = 0; lc < nlc; ++lc) {
+        const int nt = (int)(cls_task_begin[lc + 1] - cls_task_begin[lc]);
         if (nt <= 0) continue;
         void* scratch = nullptr; size_t sbytes = 0;
-        const int v = pc_class_variant(cl);
+        const int base = lc / PC_WAVE_MODES, v = pc_class_variant(base);
         if (v < 0) {
-            sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[cl]);
+            sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[lc]);
             if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return abi_rc(rc); }
             scratch = c->b_scratch.p;
         }
-        rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[cl], nt, c->b_bucket_row.as<int32_t>(),
-                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[cl], 0, c->tie_rule, pc_class_compare_only(cl), st);
+        rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[lc], nt, c->b_bucket_row.as<int32_t>(),
+                          c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[lc], 0, c->tie_rule, pc_class_compare_only(base), st,
+                          lc % PC_WAVE_MODES);
         if (rc != PC_OK) { cleanup(); return rc; }
     }
     (void)hipEventRecord(c->ev[2], st);

@@ -18,6 +18,7 @@
 struct PcDev {
     int32_t N, Wb, Wstride, G;       // genomes, bitmap words per row, row stride in u64 (odd), genes
     int32_t U, ubits;                 // distinct gene sequences; bits of a sequence rank (2^ubits >= U)
+    int32_t n_cu, pad_;               // compute units of the device these pointers live on (host-side grid sizing)
     int64_t E;                        // (genome, pham) entries
     const uint64_t* bitmap;           // [N][Wstride]
     const uint32_t* rankpre;          // [N][Wb]   entry index of the first set bit of word w of genome g
@@ -59,12 +60,19 @@ struct PcShard {
 // One wave task of the alignment kernels: column gene + a range of its bucket.
 struct PcTask { int32_t gene, begin, end, pad; };   // pad: launch class of the task (planning only)
 
+// Launch mode of a task, by how many of the workgroup's waves its rows can occupy (pc_nw_task_mode).  A task's launch class is
+// base class * PC_WAVE_MODES + mode, so the three modes of a base class are neighbours in the sorted task list and a mode with
+// too few tasks for a launch of its own is simply launched together with the one before it.
+enum { PC_MODE_CLASS = 0, PC_MODE_TWO_WAVES = 1, PC_MODE_ONE_WAVE = 2, PC_WAVE_MODES = 3 };
+
 // Per distinct column sequence q: how its bucket is cut into tasks.
 struct PcTaskPlan {
     const int32_t* task_rows;         // [U] rows per task of the main variant
     const uint8_t* q_class;           // [U] launch class (variant * 4 + lanes-per-segment bucket) of the main tasks
     const uint8_t* q_nseg;            // [U] segments per wave of the main variant
     const uint8_t* rem_class;         // [U][16] launch class for a remainder of r rows (r = n mod nseg), 255: keep them in the main task
+    int32_t nvar, small_modes;        // systolic variants; 1: tasks of at most nseg / 2 nseg rows get the one- / two-wave modes
+    int32_t variant_w[32];            // columns per lane of variant v
 };
 
 // walker modes (pc_pairs.hip)
@@ -149,6 +157,9 @@ int pc_nw_task_rows(int lb, int variant, int compare_only);     // rows per work
 int pc_nw_ppos_systolic(int variant, int max_lb); // 1: a percent-positives launch of this class can run on the systolic kernel (its profile cell)
 int pc_nw_ppos_variant(int max_lb);               // the variant to run it on when the class's own cannot; -1: general kernel
 int pc_nw_choose_remainder(int lb, int r, int main_variant);   // variant for a bucket's last r < nseg rows, -1: keep them
+int pc_nw_task_mode(int lb, int rows, int variant);            // PC_MODE_* of a task of `rows` rows on that variant
+int pc_nw_small_modes_enabled();
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, int compare_only, hipStream_t st);
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, int compare_only, hipStream_t st,
+                 int wave_mode = 0);   // wave_mode: PC_MODE_* -- workgroup shape of the launch's tasks
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

@@ -214,6 +214,8 @@ static bool mode_inc16(int W, int G, int cell_mode) {
 static int waves_for(int W, int G, int cell_mode) {
     const int Gb = pc_nw_g_bucket(G), top = pc_max_waves(W);
     const bool inc16 = mode_inc16(W, G, cell_mode);
+    static const int force_waves = getenv("PC_FORCE_WAVES") ? atoi(getenv("PC_FORCE_WAVES")) : 0;   // experiment: every workgroup with this many waves
+    if (force_waves > 0) return force_waves < top ? force_waves : top;
     if (!inc16) return PC_MIN_WAVES;
     for (int nw = PC_MIN_WAVES; nw <= top; nw *= 2)
         if ((int)((size_t)160 * 1024 / systolic_lds_bytes(W, Gb, nw, inc16)) * nw >= 16) return nw;
@@ -256,15 +258,34 @@ int pc_nw_task_rows(int lb, int variant, int compare_only) {
     int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
     const int64_t steps = task_budget() / (W + 1);
     int64_t per_stream = steps / (lb + 1); if (per_stream < 1) per_stream = 1;
-    const int64_t rows = per_stream * pc_nw_class_waves(variant, lb, compare_only) * nseg;
+    const int nw = pc_nw_class_waves(variant, lb, compare_only);
+    int64_t rows = per_stream * nw * nseg;
+    const int64_t wave_cap = (int64_t)nw * (64 / nseg) * nseg;           // a wave keeps at most 64 rows (ceil(R / (nw nseg)) nseg of the task's R)
+    if (rows > wave_cap) rows = wave_cap;
     return (int)(rows > PC_TASK_ROWS ? PC_TASK_ROWS : rows);
 }
 
+// Launch mode of a task of `rows` rows against a column gene of lb residues on variant W (host mirror of pc_task_mode in
+// pc_plan.hip).  A workgroup's waves beyond ceil(rows / nseg) find no row and leave at once, but the LDS sized for all of them
+// stays taken until the last wave is done -- with the profile cell's 20-28 KB that is five workgroups per CU with ONE live wave
+// each.  Measured on uniform 207-residue genes (tools/bucket_size_bench.py, GCUPS at 1 / 2 / 4 / 8 rows per column gene):
+// 4-wave profile-cell workgroups 452 / 894 / 1,726 / 2,344; one wave + compare cell 659 / 1,297 / 2,567 / 2,649; two waves
+// 491 / 962 / 1,907 / 2,550 (compare cell 2,681); from 16 rows the 4-wave groups win (2,956 against 2,732-2,853).
+int pc_nw_task_mode(int lb, int rows, int variant) {
+    static const int off = getenv("PC_SMALL_MODES") ? !atoi(getenv("PC_SMALL_MODES")) : 0;       // PC_SMALL_MODES=0: every task in its class's own workgroup shape
+    if (off || variant < 0 || variant >= g_num_variants || lb <= 0) return PC_MODE_CLASS;
+    const int W = g_variant_w[variant], G = (lb + W - 1) / W;
+    int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
+    return rows <= nseg ? PC_MODE_ONE_WAVE : rows <= 2 * nseg ? PC_MODE_TWO_WAVES : PC_MODE_CLASS;
+}
+int pc_nw_small_modes_enabled() { return pc_nw_task_mode(64, 1, 0) != PC_MODE_CLASS; }
+
 template <int W, int RULE>
 static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                                const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, hipStream_t st) {
+                                const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, hipStream_t st, int wave_mode) {
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
-    const int nw = waves_for(W, Gmax, cell_mode);
+    // small tasks (pc_nw_task_mode): all their rows fit one or two waves, and a workgroup sized for them leaves its LDS to others
+    const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : waves_for(W, Gmax, cell_mode);
     bool inc16 = false;
     if constexpr (W <= PC_INC16_MAX_W) inc16 = mode_inc16(W, Gmax, cell_mode);
     const int ppos = cell_mode == 2;
@@ -280,16 +301,16 @@ static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks,
 }
 template <int W>
 static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                           const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, int rule, hipStream_t st) {
+                           const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, int rule, hipStream_t st, int wave_mode) {
     switch (rule) {
-    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
-    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st);
+    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
     default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
     }
 }
@@ -304,7 +325,8 @@ size_t pc_nw_fallback_scratch_bytes(int max_lb) {
 }
 
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, int compare_only, hipStream_t st) {
+                 const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, int compare_only, hipStream_t st,
+                 int wave_mode) {
     if (ntasks <= 0) return PC_OK;
     if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_launch_nw: tie rule %d out of range", rule); return PC_ERR_ARG; }
     if (variant >= 0 && ppos && !pc_nw_ppos_systolic(variant, max_lb)) { pc_set_error("pc_launch_nw: percent-positives cannot run on variant %d for %d columns", variant, max_lb); return PC_ERR_ARG; }
@@ -313,7 +335,7 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
             pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
         }
         switch (g_variant_w[variant]) {
-#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, ppos ? 2 : (compare_only != 0 ? 1 : 0), rule, st);
+#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, ppos ? 2 : ((compare_only != 0 || wave_mode == PC_MODE_ONE_WAVE) ? 1 : 0), rule, st, wave_mode);
         PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
         PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24) PC_CASE(32) PC_CASE(48) PC_CASE(64)
 #undef PC_CASE

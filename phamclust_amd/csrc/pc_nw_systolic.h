@@ -561,12 +561,15 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
 
 // One launch of k_nw_systolic<W, RULE, INC16>; returns the hipError_t of the launch.  The only thing a translation unit
 // needs to instantiate (explicitly, in pc_nw_rules.hip; implicitly for rules 0 and 1 in pc_nw.hip).
+// (hipExtLaunchKernel's hipExtAnyOrderLaunch -- launches of one queue without the AQL barrier bit, so that a launch need not wait
+// for the last workgroup of the one before it -- is ignored on gfx950: tests/hw/anyorder_probe.hip, profiles/r04/experiments)
 template <int W, int RULE, bool INC16>
 int pc_systolic_launch(unsigned ntasks, int nw, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks,
                        const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos) {
     hipLaunchKernelGGL((k_nw_systolic<W, RULE, INC16>), dim3(ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res, ppos);
     return (int)hipGetLastError();
 }
+
 
 // X-macro over the compiled widths: PC_FOR_W2(M) for those that exist with both cells, PC_FOR_W1(M) for the wide ones
 #define PC_FOR_W2(M) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(22) M(24)

@@ -882,10 +882,14 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     // of two (N = 20,000, 5,056 phams: jc 2.06 -> 1.79 ms, af 2.89 -> 2.60, pocp 2.61 -> 2.42; below: af at N = 3,000 0.150 ms whole, 0.165 split)
     int n_chunks = (P64 + 7679) / 7680;
     if (n_chunks == 1 && P64 >= 2048 && (int64_t)d.N * sh.nown >= (int64_t)4000 * 4000) n_chunks = 2;
+    if (const char* force = getenv("PC_S64_CHUNKS")) {                              // test knob (read per launch): at least this many chunks, so that
+        const int want_chunks = atoi(force);                                        // small collections reach the one-batch instances and the forced split
+        if (want_chunks > n_chunks && want_chunks <= P64 / 64) n_chunks = want_chunks;
+    }
     const int CH = (P64 / 64 + n_chunks - 1) / n_chunks * 64;                       // equal chunks (synth(20000,20000): 5 x 4,096: jc 2.67 ms, 3 x 6,720: 2.5)
     const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
     const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
-    static const unsigned resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(2 * cus + 7) / 8u * 8u; }();
+    const unsigned resident = (unsigned)(2 * (d.n_cu > 0 ? d.n_cu : 256) + 7) / 8u * 8u;      // (the context's own device: pc_ctx_create asked it)
     // three units per workgroup (see the kernel); small matrices: one unit each, up to four times the workgroups that fit the chip
     // at once (N = 2,000: 0.158 ms with two units per workgroup, 0.129 with one)
     const unsigned want = std::max(std::min(n_units, 4u * resident), ((n_units + 2u) / 3u + 7u) / 8u * 8u);

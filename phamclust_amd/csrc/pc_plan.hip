@@ -120,6 +120,18 @@ int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const P
     return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
+// Launch class of a task = its base class (variant, lanes-per-segment bucket, any-byte) * PC_WAVE_MODES + the mode its row count
+// asks for: all rows in one wave's segments, in two waves', or the class's own workgroup (host mirror: pc_nw_task_mode).
+__device__ __forceinline__ int32_t pc_launch_class(const PcTaskPlan& tp, uint32_t base_cls, int lb, uint32_t rows) {
+    int mode = PC_MODE_CLASS;
+    const uint32_t nv4 = (uint32_t)tp.nvar * 4u;
+    if (tp.small_modes && base_cls < 2u * nv4) {                            // (the last base class is the general kernel: no modes)
+        const int W = tp.variant_w[(base_cls % nv4) / 4u], G = (lb + W - 1) / W;
+        const uint32_t nseg = (uint32_t)min(G > 64 ? 1 : 64 / G, 16);
+        mode = rows <= nseg ? PC_MODE_ONE_WAVE : rows <= 2u * nseg ? PC_MODE_TWO_WAVES : PC_MODE_CLASS;
+    }
+    return (int32_t)(base_cls * PC_WAVE_MODES + (uint32_t)mode);
+}
 __global__ void k_task_fill(PcDev d, const uint32_t* __restrict__ start_q, const uint32_t* __restrict__ end_q, PcTaskPlan tp,
                             const uint32_t* __restrict__ task_off_q, PcTask* __restrict__ tasks, int U) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,12 +139,13 @@ __global__ void k_task_fill(PcDev d, const uint32_t* __restrict__ start_q, const
     const uint32_t b = start_q[q], n = end_q[q] - b, per = (uint32_t)tp.task_rows[q];
     uint32_t rc; const uint32_t nmain = pc_split(tp, q, n, rc);
     uint32_t to = task_off_q[q];
-    const int gene = d.q_gene[q];
+    const int gene = d.q_gene[q], lb = d.gene_len[gene];
     for (uint32_t r = 0; r < nmain; r += per) {
-        PcTask t; t.gene = gene; t.begin = (int32_t)(b + r); t.end = (int32_t)(b + min(nmain, r + per)); t.pad = tp.q_class[q];
+        PcTask t; t.gene = gene; t.begin = (int32_t)(b + r); t.end = (int32_t)(b + min(nmain, r + per));
+        t.pad = pc_launch_class(tp, tp.q_class[q], lb, (uint32_t)(t.end - t.begin));
         tasks[to++] = t;
     }
-    if (rc != 255u) { PcTask t; t.gene = gene; t.begin = (int32_t)(b + nmain); t.end = (int32_t)(b + n); t.pad = (int32_t)rc; tasks[to] = t; }
+    if (rc != 255u) { PcTask t; t.gene = gene; t.begin = (int32_t)(b + nmain); t.end = (int32_t)(b + n); t.pad = pc_launch_class(tp, rc, lb, n - nmain); tasks[to] = t; }
 }
 int pc_launch_task_fill(const PcDev& d, const uint32_t* start_q, const uint32_t* end_q, const PcTaskPlan& tp, const uint32_t* task_off_q,
                         PcTask* tasks, int U, hipStream_t st) {

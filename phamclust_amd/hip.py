@@ -10,7 +10,9 @@ import weakref
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libphamclust_hip.so")
+# PHAMCLUST_NATIVE_VARIANT=hooks loads the twin compiled with -DPC_TEST_HOOKS (fault injection; one GPU test runs on it)
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                        "libphamclust_hip_hooks.so" if os.environ.get("PHAMCLUST_NATIVE_VARIANT") == "hooks" else "libphamclust_hip.so")
 METRIC_IDS = {"gcs": 0, "jc": 1, "pocp": 2, "af": 3, "aai": 4, "peq": 5, "aai_ppos": 6}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -42,7 +44,7 @@ class PcStats(ctypes.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
-EXPORTS = ["pc_version", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
+EXPORTS = ["pc_version", "pc_test_hooks", "pc_last_error", "pc_ctx_create", "pc_ctx_destroy", "pc_upload", "pc_set_shard", "pc_set_shard_balanced",
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs",
            "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev", "pc_upload_sets", "pc_upload_residues", "pc_set_plan_budget", "pc_chunk_plan",
@@ -73,6 +75,7 @@ def load():
         raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from None
     vp = ctypes.c_void_p
     L.pc_version.restype = ctypes.c_int
+    L.pc_test_hooks.restype = ctypes.c_int
     L.pc_last_error.restype = ctypes.c_char_p
     L.pc_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     L.pc_ctx_destroy.argtypes = [vp]
@@ -113,42 +116,84 @@ def _ptr(arr, typ):
     return arr.ctypes.data_as(typ)
 
 
-class BorrowedArray(np.ndarray):
-    """Result of ``Context.fill(borrow=True)``: a read-only view of page-locked memory the context owns.  The view keeps
-    the context alive (so the memory is not freed behind it by garbage collection), and once the loan has ended -- the
-    next fill or upload on the context, or its ``close()`` -- indexing it or converting it raises instead of reading
-    recycled memory.  ``x.copy()`` while the loan lasts gives an ordinary array."""
+class BorrowedArray(np.lib.mixins.NDArrayOperatorsMixin):
+    """Result of ``Context.fill(borrow=True)``: a read-only window on page-locked memory the context owns.  It keeps the
+    context alive (so the memory is not freed behind it by garbage collection), and once the loan has ended -- the next fill or
+    upload on the context, or its ``close()`` -- every way into the data raises instead of reading recycled memory.
 
-    _owner = None
-    _live = True
+    It is deliberately NOT an ``ndarray`` subclass: numpy hands an ndarray subclass's buffer to ``np.asarray`` /
+    ``np.ascontiguousarray`` without asking it (r03's class was one, and those two read a dead loan silently).  Being a foreign
+    object, everything numpy does with it starts at ``__array__`` / ``__array_ufunc__`` / ``__array_function__``, and all three
+    check the loan.  While the loan lasts, those calls see an ordinary read-only view (zero copy); ``x.copy()`` gives an
+    array that owns its memory.  What cannot be guarded is a plain view or pointer taken while the loan was alive and kept."""
 
-    def _begin_loan(self, owner):
-        self._owner, self._live = owner, True
+    __slots__ = ("_view", "_owner", "_live", "_root", "__weakref__")
+
+    def __init__(self, view, owner, root=None):
+        self._view, self._owner, self._live = view, owner, True
+        self._root = self if root is None else root         # slices of a loan share its fate through the root object
 
     def _end_loan(self):
         self._live, self._owner = False, None
 
-    def __array_finalize__(self, obj):
-        if isinstance(obj, BorrowedArray):          # slices of a loan share its fate through the root object
-            self._root = getattr(obj, "_root", obj)
-
     def _check_loan(self):
-        if not getattr(self, "_root", self)._live:
+        if not self._root._live:
             raise HipLibraryError("this array was lent by Context.fill(borrow=True) and the loan has ended (a later fill / "
                                   "upload / close on the context recycled its memory); copy it while it is valid")
 
+    shape = property(lambda self: self._view.shape)
+    dtype = property(lambda self: self._view.dtype)
+    size = property(lambda self: self._view.size)
+    ndim = property(lambda self: self._view.ndim)
+    nbytes = property(lambda self: self._view.nbytes)
+
+    def __len__(self):
+        return len(self._view)
+
     def __getitem__(self, item):
         self._check_loan()
-        return super().__getitem__(item)
+        got = self._view[item]
+        return BorrowedArray(got, None, self._root) if isinstance(got, np.ndarray) and got.base is not None else got
+
+    def __iter__(self):
+        self._check_loan()
+        return iter(self._view)
 
     def __array__(self, dtype=None, copy=None):
         self._check_loan()
-        out = self.view(np.ndarray)
-        return out.astype(dtype) if dtype is not None and dtype != out.dtype else (out.copy() if copy else out)
+        if dtype is not None and np.dtype(dtype) != self._view.dtype:
+            return self._view.astype(dtype)
+        return self._view.copy() if copy else self._view
 
     def copy(self, order="C"):
         self._check_loan()
-        return np.array(self.view(np.ndarray), order=order, copy=True)
+        return np.array(self._view, order=order, copy=True)
+
+    def __getattr__(self, name):                             # .max(), .sum(), .tolist(), .astype() ...: the view's, after the check
+        if name.startswith("_"):
+            raise AttributeError(name)
+        self._check_loan()
+        return getattr(self._view, name)
+
+    @staticmethod
+    def _plain(x):
+        if isinstance(x, BorrowedArray):
+            x._check_loan()
+            return x._view
+        if isinstance(x, (list, tuple)):
+            return type(x)(BorrowedArray._plain(y) for y in x)
+        if isinstance(x, dict):
+            return {k: BorrowedArray._plain(v) for k, v in x.items()}
+        return x
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return getattr(ufunc, method)(*self._plain(inputs), **self._plain(kwargs))
+
+    def __array_function__(self, func, types, args, kwargs):
+        return func(*self._plain(args), **self._plain(kwargs))
+
+    def __repr__(self):
+        return f"BorrowedArray({'live' if self._root._live else 'loan ended'}, shape={self.shape}, dtype={self.dtype})"
 
 
 class Context:
@@ -273,9 +318,9 @@ class Context:
         if borrow:
             ptr = _f64p()
             self._check(self._lib.pc_fill_borrow(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.byref(ptr), ctypes.byref(stats)))
-            out = np.ctypeslib.as_array(ptr, shape=(max(self.n_pairs, 1),))[:self.n_pairs].view(BorrowedArray)
-            out.flags.writeable = False
-            out._begin_loan(self)
+            view = np.ctypeslib.as_array(ptr, shape=(max(self.n_pairs, 1),))[:self.n_pairs]
+            view.flags.writeable = False
+            out = BorrowedArray(view, self)
             self._loans.append(weakref.ref(out))
             return (out, stats.as_dict()) if want_stats else out
         out = np.empty(max(self.n_pairs, 0), dtype=np.float64)

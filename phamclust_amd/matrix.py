@@ -344,8 +344,9 @@ def matrix_de_novo(genomes, func, cpus, as_distance=True):
     (matrix.py:471-472), this spreads them over the GPUs of the job it runs in: under
     ``python -m torch.distributed.run --nproc-per-node N`` (one process per GPU; ``phamclust --gpus N`` starts that
     for you) every rank calls this with the same genomes, fills its static shard of the pair list, and ONE gather
-    brings the shards to rank 0.  Rank 0 returns the matrix; every other rank returns ``None``.  ``cpus`` itself is
-    accepted for signature compatibility only.
+    brings the shards to rank 0.  Rank 0 returns the matrix; every other rank returns ``None``.  For those six, ``cpus`` is
+    accepted for signature compatibility only; any OTHER callable is filled the reference's way -- per pair, in its batch
+    order, over ``cpus`` joblib workers (in this process when ``cpus`` is 1).
     """
     if len(genomes) == 0:
         raise ValueError("need at least 1 genome to construct matrix de novo")
@@ -376,16 +377,43 @@ def matrix_de_novo(genomes, func, cpus, as_distance=True):
             return None
         return SymMatrix.from_condensed(names, condensed, is_distance=as_distance)
 
-    # any other callable: the reference's per-pair semantics, in its batch order
+    # any other callable: the reference's per-pair semantics, its batch order, its worker pool (matrix.py:460-493)
+    n = len(genomes)
+    n_pairs = n * (n - 1) // 2 + n
+    if n_pairs < cpus:                                  # (matrix.py:460-462)
+        logging.info(f"small dataset - reducing # CPUs to {n_pairs}")
+        cpus = n_pairs
     matrix = SymMatrix(nodes=names, is_distance=as_distance)
     for genome in genomes:
         matrix.set_weight(genome.name, genome.name, 1.0 - as_distance)
-    for i in _outside_in_index_iterator(len(genomes)):
-        source = genomes[i]
-        for target in genomes[i + 1:]:
-            s, t, w = calculate_adjacency(source, target, func, as_distance)
-            matrix.set_weight(s, t, w)
+    order = list(_outside_in_index_iterator(n))
+    if cpus is None or cpus <= 1:
+        for i in order:
+            source = genomes[i]
+            for target in genomes[i + 1:]:
+                s, t, w = calculate_adjacency(source, target, func, as_distance)
+                matrix.set_weight(s, t, w)
+        return matrix
+    # Batches of `stride` source rows in outside-in order hold about 10,000 pairs per worker (matrix.py:474-478); inside a batch
+    # one task is one SOURCE ROW cut into pieces of at most 2,500 targets -- the reference pickles both genomes of every pair
+    # (matrix.py:484-488), this sends a source once per piece -- and results come back in whatever order the workers finish.
+    import joblib
+    stride = max(1, int(n // (n_pairs / (10000 * cpus))))
+    runner = joblib.Parallel(n_jobs=cpus, return_as="generator_unordered", max_nbytes=None)
+    for b0 in range(0, n, stride):
+        rows = order[b0:b0 + stride]
+        pieces = [(genomes[i], genomes[j0:min(j0 + 2500, n)]) for i in rows for j0 in range(i + 1, n, 2500)]
+        for edges in runner(joblib.delayed(_row_adjacency)(source, targets, func, as_distance) for source, targets in pieces):
+            for s, t, w in edges:
+                matrix.set_weight(s, t, w)
+        logging.debug(f"finished {', '.join(genomes[i].name for i in rows)}")
+    del runner
     return matrix
+
+
+def _row_adjacency(source, targets, func, distance):
+    """One worker task of the generic path: ``source`` against a run of targets."""
+    return [calculate_adjacency(source, target, func, distance) for target in targets]
 
 
 # ---------------------------------------------------------------------------------------

@@ -68,5 +68,16 @@ ACCELERATED = {gene_content_similarity: "gcs", jaccard_coefficient: "jc",
                percentage_of_conserved_proteins: "pocp", alignment_fraction: "af",
                average_aminoacid_identity: "aai", proteomic_equivalence_quotient: "peq"}
 
+# What every report of an aai / peq number says about parity: the aligner restates parasail's co-optimal tie-breaking
+# from recall -- parasail itself is not in reach -- so those two metrics are pinned only where mathematics pins them.
+PARITY_NOTE = {"aai": "aai/peq aligner unpinned vs parasail (co-optimal ties); 82.4 % of alignments certified rule-independent",
+               "peq": "aai/peq aligner unpinned vs parasail (co-optimal ties); 82.4 % of alignments certified rule-independent"}
+
+
+def parity_note(metric):
+    """The parity caveat a log line or bench record of ``metric`` carries; gcs / jc / pocp / af are pinned by reference fixtures."""
+    return PARITY_NOTE.get(metric, "pinned: bit-exact vs fixtures written by the live reference")
+
+
 __all__ = ["alignment_fraction", "average_aminoacid_identity", "gene_content_similarity",
            "jaccard_coefficient", "percentage_of_conserved_proteins", "proteomic_equivalence_quotient"]

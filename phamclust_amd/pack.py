@@ -240,6 +240,12 @@ def load_tsv_packed(filepath):
     return _load_tsv(filepath, keep_handle=False)[0]
 
 
+def _plain_genome(name, phams):
+    genome = Genome(name)
+    genome.phams = phams
+    return genome
+
+
 class LazyGenome(Genome):
     """A ``Genome`` whose genes still live in the loader's packed arrays.  ``phams`` (pham -> translations, in the
     genome's own insertion order) is built on first use; the FASTA text -- what the pipeline hashes and stashes --
@@ -251,20 +257,28 @@ class LazyGenome(Genome):
         self._packed, self._owner, self._index = packed, owner, index
         self._phams = None
 
+    def _read_phams(self):
+        pk, g = self._packed, self._index
+        k0, k1 = int(pk.gene_off[g]), int(pk.gene_off[g + 1])
+        genes = sorted(range(k0, k1), key=lambda k: int(pk.gene_order[k]))
+        text = pk.residues[int(pk.seq_off[k0]):int(pk.seq_off[k1])].tobytes().decode("latin-1")
+        base = int(pk.seq_off[k0])
+        found = {}
+        for k in genes:
+            found.setdefault(pk.pham_names[int(pk.gene_pham[k])], []).append(
+                text[int(pk.seq_off[k]) - base:int(pk.seq_off[k + 1]) - base])
+        return found
+
     @property
     def phams(self):
         if self._phams is None:
-            pk, g = self._packed, self._index
-            k0, k1 = int(pk.gene_off[g]), int(pk.gene_off[g + 1])
-            genes = sorted(range(k0, k1), key=lambda k: int(pk.gene_order[k]))
-            text = pk.residues[int(pk.seq_off[k0]):int(pk.seq_off[k1])].tobytes().decode("latin-1")
-            base = int(pk.seq_off[k0])
-            found = {}
-            for k in genes:
-                found.setdefault(pk.pham_names[int(pk.gene_pham[k])], []).append(
-                    text[int(pk.seq_off[k]) - base:int(pk.seq_off[k + 1]) - base])
-            self._phams = found
+            self._phams = self._read_phams()
         return self._phams
+
+    def __reduce__(self):
+        """Pickled (joblib workers of the generic ``matrix_de_novo`` path), a lazy genome travels as a plain ``Genome``: the
+        loader's arrays and its C handle stay in this process, and the object itself stays attached to them."""
+        return _plain_genome, (self.name, self._read_phams() if self._phams is None else self._phams)
 
     @phams.setter
     def phams(self, value):

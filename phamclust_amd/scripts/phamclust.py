@@ -21,6 +21,7 @@ import numpy as np
 
 from phamclust_amd import distributed
 from phamclust_amd import matrix as _matrix
+from phamclust_amd import metrics as _metrics
 from phamclust_amd.cli import METRICS, parse_args
 from phamclust_amd.clustering import hierarchical_clustering
 from phamclust_amd.genome import Genome
@@ -171,6 +172,8 @@ class _Run:
                 line += (f"; rank 0: {st['n_alignments']} alignments, {st['n_cells']:.3e} DP cells, "
                          f"{st['n_distinct_cells'] / max(st['ms_align'], 1e-6) / 1e6:.0f} GCUPS in the alignment kernels")
             log.info(line)
+            if self.metric in _metrics.PARITY_NOTE:          # say it wherever these numbers leave the program
+                log.info(f"parity: {_metrics.parity_note(self.metric)}")
             matrix_to_squareform(matrix, cached, lower_triangle=True)
         if not matrix.is_distance:
             matrix.invert()

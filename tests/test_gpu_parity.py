@@ -1064,7 +1064,8 @@ def test_chunked_fill_is_the_unchunked_matrix(gpu_ctx, native_built):
 
 def test_out_of_memory_plan_becomes_smaller_chunks(native_built):
     """A device allocation that fails inside a fill is answered with smaller chunks, not with PC_ERR_HIP.  The failure is
-    injected (PC_FAKE_OOM_ABOVE: allocations above that many bytes fail), so this runs in its own process."""
+    injected (PC_FAKE_OOM_ABOVE: allocations above that many bytes fail) -- a switch that exists only in the library's
+    -DPC_TEST_HOOKS twin (libphamclust_hip_hooks.so, PHAMCLUST_NATIVE_VARIANT=hooks), so this runs in its own process."""
     import subprocess
     import sys
     code = r'''
@@ -1074,6 +1075,7 @@ from phamclust_amd import hip
 from phamclust_amd.synth import synth_packed
 from oracle import oracle as O
 pk = synth_packed(260, 1500, seed=3)
+assert hip.load().pc_test_hooks() == 1, "not the hooks build"
 with hip.Context(0) as ctx:
     ctx.upload(pk)
     got, st = ctx.fill("peq", want_stats=True)
@@ -1081,10 +1083,16 @@ with hip.Context(0) as ctx:
     assert np.array_equal(got, O.fill(pk, "peq")), "chunked-after-OOM fill differs from the oracle"
     print("chunks", st["n_chunks"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19))       # ~0.1 M alignments: the one-piece plan's A * 8-byte buffers are ~0.9 MB
+    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19), PHAMCLUST_NATIVE_VARIANT="hooks")       # ~0.1 M alignments: the one-piece plan's A * 8-byte buffers are ~0.9 MB
     run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "chunks" in run.stdout
+    # the release library has no such switch: the same environment changes nothing there
+    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19))
+    env.pop("PHAMCLUST_NATIVE_VARIANT", None)
+    code2 = code.replace('== 1, "not the hooks build"', '== 0, "the release build carries test hooks"').replace('assert st["n_chunks"] >= 2, st', 'assert st["n_chunks"] == 1, st')
+    run = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
 
 
 def test_two_part_upload(gpu_ctx, native_built):
@@ -1162,7 +1170,11 @@ def test_borrowed_result_loan(gpu_ctx, native_built):
         lent[0]
     with pytest.raises(hip.HipLibraryError, match="loan has ended"):
         lent.copy()
-    assert again[0] >= 0.0
+    with pytest.raises(hip.HipLibraryError, match="loan has ended"):      # ufuncs and reductions as well
+        np.sum(lent)
+    with pytest.raises(hip.HipLibraryError, match="loan has ended"):
+        lent + 1.0
+    assert again[0] >= 0.0 and float(np.sum(again)) == float(np.sum(again.copy()))
     gpu_ctx.upload(packed)
     with pytest.raises(hip.HipLibraryError):
         again.copy()
@@ -1199,7 +1211,8 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
     O = _oracle()
     rng = np.random.default_rng(11)
     packed = _set_kernel_case(rng, 150, 40000, wide_rows=(3, 77, 149), shared_by_all=(5, 4100, 39999))
-    assert packed.words_per_row * 64 > 7680                                  # more than one mask chunk of the 64 x 64 kernel
+    assert packed.words_per_row * 64 > 7680                                  # (the VOCABULARY; the 64 x 64 kernel chunks over the phams with two holders
+    #                                                                          or more -- ~1,300 here: test_sparse64_chunked_instances_and_forced_split drives that count)
     want = {(m, dist): O.fill(packed, m, dist) for m in ("pocp", "af") for dist in (True, False)}
     stream = torch.cuda.current_stream().cuda_stream
     try:
@@ -1230,7 +1243,7 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
         # one mask chunk of more than 64 KB of LDS (5,952 < phams <= 7,680)
         os.environ["PC_SET_KERNEL"] = "sparse64"
         mid = _set_kernel_case(rng, 120, 25000, wide_rows=(9,))
-        assert 5952 < mid.words_per_row * 64 <= 7680
+        assert 5952 < mid.words_per_row * 64 <= 7680                          # (again the vocabulary, see above)
         gpu_ctx.upload(mid, residues=False)
         for m in ("pocp", "af", "gcs", "jc"):
             assert np.array_equal(gpu_ctx.fill(m), O.fill(mid, m)), m
@@ -1254,6 +1267,89 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
             assert np.array_equal(gpu_ctx.fill(m), O.fill(odd, m)), m
     finally:
         os.environ.pop("PC_SET_KERNEL", None)
+        gpu_ctx.set_shard(0, 1)
+
+
+def _dense_phams(packed):
+    """Phams with at least two holders: what k_sparse_tile64's lists and mask chunks cover (k_sp_build renumbers them densely)."""
+    bits = np.unpackbits(packed.bitmap.reshape(packed.n_genomes, packed.words_per_row).view(np.uint8), axis=1, bitorder="little")
+    return int((bits.sum(axis=0) >= 2).sum())
+
+
+def _two_holder_case(rng, n_genomes, per_genome, wide=None, extra_holders=0):
+    """Every pham of the pool is held by exactly two genomes (then `extra_holders` random ones get a third ... holder), so the dense
+    pham count is the pool size n_genomes * per_genome / 2 -- whatever the vocabulary; `wide` = (genome, entries) gets a long row."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    pool = n_genomes * per_genome // 2
+    slots = np.repeat(np.arange(pool), 2)
+    rng.shuffle(slots)
+    held = [set() for _ in range(n_genomes)]
+    for k, p in enumerate(slots):                           # deal the shuffled (pham, pham) list round: a genome rarely gets both copies
+        g = k % n_genomes
+        if int(p) in held[g]:
+            g = (g + 1) % n_genomes
+        held[g].add(int(p))
+    for p in rng.choice(pool, size=extra_holders, replace=False):
+        for g in rng.choice(n_genomes, size=int(rng.integers(3, 40)), replace=False):
+            held[int(g)].add(int(p))                        # phams with many holders: masks with many bits (broadcast adds)
+    if wide is not None:
+        held[wide[0]] |= set(int(x) for x in rng.choice(pool, size=wide[1], replace=False))
+    genomes = []
+    for k in range(n_genomes):
+        g = Genome(f"g{k:04d}")
+        for p in sorted(held[k]):
+            for _ in range(int(rng.integers(2, 5)) if p % 7 == 0 else 1):      # paralogs: pocp's second direction
+                g.add(f"p{p:05d}", "M" * int(rng.integers(1, 40)))
+        g.add(f"own{k:04d}", "MK")                          # a pham nobody else holds: dropped from the dense numbering
+        genomes.append(g)
+    return pack_genomes(genomes)
+
+
+def test_sparse64_chunked_instances_and_forced_split(gpu_ctx, native_built):
+    """k_sparse_tile64<*, 1> -- the one-batch instances every gcs / jc / pocp / af fill takes once the masks are split, i.e.
+    from ~4,000 genomes and for every collection of more than 7,680 shareable phams (nothing reached them at test
+    size, because the kernel chunks over the phams with at least two holders, not over the vocabulary).  Here the dense count
+    itself is driven past 7,680 (two equal chunks, ~100 entries per row and chunk: the overflow loop behind the 64-entry batch),
+    a second collection sits between 5,952 and 7,680 (one chunk of more than 64 KB of dynamic LDS, two-batch instances, a
+    300-entry row for their overflow loop), and PC_S64_CHUNKS forces the split -- 2 and 3 chunks -- on it.  All four metrics,
+    similarity and distance, and a shard, against the oracle (metrics.py:26-157)."""
+    import torch
+    O = _oracle()
+    rng = np.random.default_rng(23)
+    big = _two_holder_case(rng, 150, 200, wide=(77, 900), extra_holders=60)
+    mid = _two_holder_case(rng, 136, 100, wide=(9, 300), extra_holders=40)
+    assert _dense_phams(big) > 7680 and 5952 < _dense_phams(mid) <= 7680, (_dense_phams(big), _dense_phams(mid))
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        os.environ["PC_SET_KERNEL"] = "sparse64"
+        for label, packed, chunks in (("big", big, None), ("mid", mid, None), ("mid", mid, "2"), ("mid", mid, "3"), ("big", big, "5")):
+            if chunks is None:
+                os.environ.pop("PC_S64_CHUNKS", None)
+            else:
+                os.environ["PC_S64_CHUNKS"] = chunks                        # read per launch
+            gpu_ctx.upload(packed, residues=False)
+            for m in ("gcs", "jc", "pocp", "af"):
+                for dist in (True, False):
+                    assert np.array_equal(gpu_ctx.fill(m, dist), O.fill(packed, m, dist)), (label, chunks, m, dist)
+            gpu_ctx.set_shard(2, 3)
+            t_rank, t_lbase = gpu_ctx.shard_table()
+            n = packed.n_genomes
+            for m in ("jc", "pocp", "af"):
+                w = O.fill(packed, m, True)
+                buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
+                gpu_ctx.fill_shard_dev(m, True, buf.data_ptr(), stream)
+                torch.cuda.synchronize()
+                got = buf.cpu().numpy()
+                for t in range(1, n):
+                    if t_rank[t] != 2:
+                        continue
+                    col = np.array([w[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
+                    assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), (label, chunks, m, t)
+            gpu_ctx.set_shard(0, 1)
+    finally:
+        os.environ.pop("PC_SET_KERNEL", None)
+        os.environ.pop("PC_S64_CHUNKS", None)
         gpu_ctx.set_shard(0, 1)
 
 

@@ -221,6 +221,43 @@ def test_matrix_de_novo_generic_callable_and_errors():
     assert not sim.is_distance and sim.get_weight("g1", "g1") == 1.0 and sim.get_weight("g1", "g2") == 0.5
 
 
+def _toy_shared_fraction(source, target, as_distance=False):
+    """A metric that is none of the six METRICS: matrix_de_novo's generic path (module level: joblib pickles it by name)."""
+    union = len(source | target)
+    sim = len(source & target) / union if union else 0.0
+    return round(1.0 - sim, 6) if as_distance else round(sim, 6)
+
+
+def test_generic_callable_over_cpus_equals_one_process(native_built):
+    """matrix.py:471-493: ANY callable is spread over `cpus` workers.  cpus=2 (joblib, unordered results) must give the
+    matrix cpus=1 gives, for plain genomes and for the C loader's lazy genomes (which pickle as plain ones and stay lazy)."""
+    import random
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.matrix import matrix_de_novo
+    from phamclust_amd.pack import load_tsv_genomes, packed_behind
+    rng = random.Random(5)
+    gs = []
+    for k in range(37):
+        g = Genome(f"g{k:02d}")
+        for p in rng.sample(range(60), rng.randint(1, 25)):
+            g.add(f"p{p}", "MK" * rng.randint(1, 4))
+        gs.append(g)
+    one = matrix_de_novo(gs, _toy_shared_fraction, 1)
+    two = matrix_de_novo(gs, _toy_shared_fraction, 2)
+    assert one.nodes == two.nodes and np.array_equal(one.to_ndarray(), two.to_ndarray())
+    assert len({one.get_weight(a.name, b.name) for a in gs for b in gs}) > 20        # not a constant matrix
+    lazy = load_tsv_genomes(os.path.join(REPO, "tests", "golden", "small_input.tsv"))
+    m1 = matrix_de_novo(lazy, _toy_shared_fraction, 1, as_distance=False)
+    assert packed_behind(lazy) is None                          # cpus=1 read .phams in this process: detached
+    lazy = load_tsv_genomes(os.path.join(REPO, "tests", "golden", "small_input.tsv"))
+    m3 = matrix_de_novo(lazy, _toy_shared_fraction, 3, as_distance=False)
+    assert packed_behind(lazy) is not None                      # the workers got plain copies; the originals stayed lazy
+    assert np.array_equal(m1.to_ndarray(), m3.to_ndarray())
+    # more workers than pairs: clamped like the reference (matrix.py:460-462)
+    tiny = matrix_de_novo(gs[:2], _toy_shared_fraction, 64)
+    assert tiny.get_weight("g00", "g01") == one.get_weight("g00", "g01")
+
+
 def test_cli_surface():
     from phamclust_amd import cli
     assert list(cli.METRICS) == ["gcs", "jc", "pocp", "af", "aai", "peq"]
@@ -245,8 +282,41 @@ def test_abi_exports_match_header(native_built):
     for name in declared:
         assert hasattr(lib, name), name
     assert hip.load().pc_version() == int(re.search(r"#define\s+PC_VERSION\s+(\d+)", header).group(1)) >= 110
+    # the release library carries no fault injection; its -DPC_TEST_HOOKS twin exports the same ABI and says what it is
+    assert hip.load().pc_test_hooks() == 0
+    twin = ctypes.CDLL(os.path.join(os.path.dirname(hip.LIB_PATH), "libphamclust_hip_hooks.so"))
+    for name in declared:
+        assert hasattr(twin, name), name
+    assert twin.pc_test_hooks() == 1 and twin.pc_version() == hip.load().pc_version()
+    assert b"PC_FAKE_OOM_ABOVE" not in open(hip.LIB_PATH, "rb").read()
     assert ctypes.sizeof(hip.PcPacked) == 16 + 8 * 8 and ctypes.sizeof(hip.PcStats) == 5 * 8 + 2 * 4 + 4 * 4 + 2 * 8
     assert "n_chunks" in hip.PcStats().as_dict()
+
+
+def test_borrowed_array_guards_every_numpy_route():
+    """a lent result must refuse ufuncs, reductions and numpy functions too once its loan has ended, not only
+    indexing and conversion (host logic: the view class itself, over ordinary memory)."""
+    from phamclust_amd import hip
+
+    class Owner:
+        pass
+    base = np.arange(12, dtype=np.float64)
+    lent = hip.BorrowedArray(base.view(), Owner())
+    part = lent[2:5]                                          # a slice shares the loan
+    assert lent.shape == (12,) and len(part) == 3 and lent.dtype == np.float64 and float(lent[3]) == 3.0
+    assert type(np.asarray(lent)) is np.ndarray and np.array_equal(lent, base) and list(part) == [2.0, 3.0, 4.0]
+    assert float(np.sum(lent)) == 66.0 and type(lent + 1) is np.ndarray and (lent + 1)[0] == 1.0
+    assert type(np.ascontiguousarray(lent)) is np.ndarray and np.concatenate([lent, part]).shape == (15,)
+    assert float(part.max()) == 4.0 and float(np.dot(lent, lent)) == float(np.dot(base, base))
+    into = np.zeros(12)
+    np.add(lent, 1.0, out=into)
+    assert into[3] == 4.0
+    lent._end_loan()
+    for use in (lambda: lent[0], lambda: lent.copy(), lambda: np.asarray(lent), lambda: np.sum(lent), lambda: lent + 1, lambda: lent.max(),
+                lambda: np.ascontiguousarray(lent), lambda: np.concatenate([base, lent]), lambda: np.add(base, lent, out=into),
+                lambda: part[0], lambda: part * 2.0, lambda: np.mean(part)):
+        with pytest.raises(hip.HipLibraryError, match="loan has ended"):
+            use()
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -298,3 +298,26 @@ def test_bulk_fill_equals_pairwise_for_every_metric():
             want = np.array([O.pair(pk, metric, s, t, as_distance=as_distance) for s in range(n) for t in range(s + 1, n)])
             assert np.array_equal(f, want), (metric, as_distance)
     assert (O.fill(pk, "aai_ppos", False) >= O.fill(pk, "aai", False)).all()
+
+
+def test_checker_refuses_to_answer_with_switched_conventions():
+    """pco_set_gap / pco_set_compat are process-global; a stray call must not turn later comparisons into ones
+    against another aligner.  The matrix entry points answer under the defaults, or inside the scoped switches, only."""
+    from oracle import oracle as O
+    from phamclust_amd.synth import synth_packed
+    pk = synth_packed(6, 60, seed=2)
+    base = O.fill(pk, "peq")
+    with O.gap(12, 1):
+        other = O.fill(pk, "peq")                               # on purpose: allowed
+    assert np.array_equal(O.fill(pk, "peq"), base) and other.shape == base.shape
+    with O.compat(case_sensitive=True):
+        O.pairs(pk, "aai", [0], [1])
+    O.set_gap(12, 1)                                            # a bare call leaves the library switched ...
+    try:
+        for call in (lambda: O.fill(pk, "peq"), lambda: O.pairs(pk, "aai", [0], [1]), lambda: O.pair(pk, "peq", 0, 1),
+                     lambda: O.fill_rows(pk, "peq", 0, 2)):
+            with pytest.raises(RuntimeError, match="left switched"):
+                call()
+    finally:
+        O.set_gap()                                             # ... until the defaults are restored
+    assert np.array_equal(O.fill(pk, "peq"), base)

@@ -78,29 +78,26 @@ def conventions(O, packed, s_idx, t_idx):
     base = {m: O.pairs(packed, m, s_idx, t_idx, as_distance=False) for m in ("aai", "peq")}
     out = {"residues": int(res.size), "lower_case_residues": n_lower, "residues_outside_the_24_letters": n_other, "switches": []}
 
-    def measure(name, touches, setup, teardown, what):
+    def measure(name, touches, switched, what):
         row = {"switch": name, "what": what, "residues_it_can_touch": touches}
         if touches == 0:
             row.update({"aai_moved_gt_1e-6_frac": 0.0, "peq_moved_gt_1e-6_frac": 0.0, "max_abs_d_aai": 0.0, "max_abs_d_peq": 0.0,
                         "note": "no residue of this data set is affected: exposure is zero by construction"})
         else:
-            setup()
-            try:
+            with switched:                                   # the checker's defaults are back when the block ends
                 for m in ("aai", "peq"):
                     d = np.abs(O.pairs(packed, m, s_idx, t_idx, as_distance=False) - base[m])
                     row[f"{m}_moved_gt_1e-6_frac"] = float((d > 1e-6).mean())
                     row[f"max_abs_d_{m}"] = float(d.max())
-            finally:
-                teardown()
         out["switches"].append(row)
 
-    measure("case_sensitive_identity", n_lower, lambda: O.set_compat(case_sensitive=True), O.set_compat,
+    measure("case_sensitive_identity", n_lower, O.compat(case_sensitive=True),
             "item 6: '|' only for byte-equal residues (default: case-insensitive)")
-    measure("lower_case_outside_alphabet", n_lower, lambda: O.set_compat(lower_unknown=True), O.set_compat,
+    measure("lower_case_outside_alphabet", n_lower, O.compat(lower_unknown=True),
             "item 7: lower-case letters score as an unknown byte (default: like upper case)")
-    measure("unknown_byte_scores_as_X", n_other, lambda: O.set_compat(unknown_row=22), O.set_compat,
+    measure("unknown_byte_scores_as_X", n_other, O.compat(unknown_row=22),
             "item 7: a byte outside the alphabet takes the X row (default: the * row)")
-    measure("gap_of_k_costs_open_plus_k_extend", int(res.size), lambda: O.set_gap(12, 1), O.set_gap,
+    measure("gap_of_k_costs_open_plus_k_extend", int(res.size), O.gap(12, 1),
             "item 2: the other affine convention (BLAST's), i.e. the same recurrence with open = 12 (default: 11 + (k-1))")
     return out
 
