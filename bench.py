@@ -188,6 +188,11 @@ def main():
         build.build_all()                 # no-op when the in-tree libraries are current; one rank only
     if world > 1:
         dist.barrier()
+    # What a rank costs before it can fill anything (never part of `value`): this process's own start -- interpreter, torch
+    # import, process-group init -- up to the first barrier all ranks pass.  Max over ranks below.  (The launcher's own
+    # start-up is on top: tools/launch_cost.py measures the whole command.)
+    from phamclust_amd.startup import process_start_time
+    init_s = time.time() - process_start_time()
 
     packed = synth_packed(a.genomes, a.phams)
     ctx = hip.Context(local_rank)
@@ -342,6 +347,20 @@ def main():
     else:
         line["stage_ms"] = stage_multi
         line["shards"] = shard_span
+        # the fixed cost of being N ranks, and the rate a user of one matrix sees with it: process start -> group ready (max over
+        # ranks), + one upload, + one fill with its exchange (the timed step)
+        t = torch.tensor([init_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        line["init_s"] = float(t.item())
+        t0 = time.perf_counter()
+        ctx.upload(packed, residues=needs_residues)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        line["upload_s"] = float(t.item())
+        line["value_wall_incl_init"] = n_pairs / (line["init_s"] + line["upload_s"] + elapsed / a.steps) if n_pairs else 0.0
+        line["init_note"] = ("init_s: process start -> torch imported, process group initialised, first barrier passed (max over ranks); "
+                             "value_wall_incl_init = pairs / (init_s + upload_s + one step): what ONE matrix costs a job that has to start its ranks first")
 
     if a.verify_pairs > 0 and n_pairs > 0:
         # sampled check of the assembled matrix against the oracle (random pairs over the whole triangle)

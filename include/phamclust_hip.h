@@ -222,6 +222,11 @@ int pc_variant_width(int lb);
 /* Test / tuning hook: HIP-event milliseconds of the alignment kernels of the last pc_align_pairs call. */
 float pc_last_align_ms(const pc_ctx* ctx);
 
+/* Which kernel family the selector gave the last gcs / jc / pocp / af fill of this context: 0 popcount tiles, 1 sparse tiles
+ * 32 x 32, 2 sparse tiles 64 x 64, 3 shared-pham walker; -1 before the first such fill.  (The selector reads the collection:
+ * genomes, bitmap words, phams an average pair shares -- metrics.py:26-157 have one code path, this has four.) */
+int pc_last_set_kernel(const pc_ctx* ctx);
+
 /* Test hook: the device implementation of Python's round(x, 6) (the rounding every metric
  * returns through, e.g. metrics.py:50-53) applied to n host doubles in [0, 2^20). */
 int pc_round6_probe(pc_ctx* ctx, const double* in, double* out, int64_t n);

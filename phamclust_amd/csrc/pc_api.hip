@@ -191,6 +191,7 @@ struct pc_ctx {
     hipEvent_t ev_last = nullptr;           // recorded at the end of every entry point that leaves work on a caller's stream
     bool busy = false;                      // ev_last was recorded and not waited for yet
     hipStream_t last_stream = nullptr;      // ... on this stream
+    int last_set_kernel = -1;               // kernel family the last gcs / jc / pocp / af fill ran on (pc_last_set_kernel)
     int64_t plan_budget = 0;                // bytes of plan buffers one chunk of an aai / peq fill may use; 0: automatic (pc_set_plan_budget)
 };
 
@@ -299,20 +300,30 @@ static void build_code_lut(uint8_t lut[256]) {
     for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)assigned[i];
 }
 
-// Launch class of a column gene: variant * 4 + bucket of lanes per segment (<=8, <=16, <=32, <=64); the same again,
+// Base class of a column gene: variant * 4 + bucket of lanes per segment (<=8, <=16, <=32, <=64); the same again,
 // nvar * 4 higher, for column genes that hold a byte outside the 24-letter alphabet ("any byte" classes: they must run
-// the residue-compare cell, see pc_common.h); last class: the general kernel.
-static int pc_num_classes() { return pc_nw_num_variants() * 8 + 1; }
+// the residue-compare cell, see pc_common.h); then one class per wide variant for column genes longer than its 64 x W columns
+// (strip-mined passes, k_nw_strip); last class: the general kernel.
+#define PC_STRIP_CLASSES 3                                 // W = 32, 48, 64: the last three variants
+static int pc_num_classes() { return pc_nw_num_variants() * 8 + PC_STRIP_CLASSES + 1; }
 static int pc_class_of(int lb, int variant, bool any_byte) {
     const int nvar = pc_nw_num_variants();
-    if (variant < 0) return nvar * 8;
+    if (variant < 0) return nvar * 8 + PC_STRIP_CLASSES;
     const int W = pc_nw_variant_w(variant);
+    if (lb > 64 * W) return nvar * 8 + std::max(0, variant - (nvar - PC_STRIP_CLASSES));       // strip-mined (the chooser only picks a wide variant for these)
     const int Gs = (lb + W - 1) / W;
     const int Gb = pc_nw_g_bucket(Gs);
     return variant * 4 + (Gb == 8 ? 0 : Gb == 16 ? 1 : Gb == 32 ? 2 : 3) + (any_byte && !pc_nw_variant_takes_any_byte(variant) ? nvar * 4 : 0);
 }
-static int pc_class_variant(int cls) { const int nvar = pc_nw_num_variants(); return cls >= nvar * 8 ? -1 : (cls % (nvar * 4)) / 4; }
+static int pc_class_variant(int cls) {
+    const int nvar = pc_nw_num_variants();
+    if (cls >= nvar * 8 + PC_STRIP_CLASSES) return -1;
+    if (cls >= nvar * 8) return nvar - PC_STRIP_CLASSES + (cls - nvar * 8);
+    return (cls % (nvar * 4)) / 4;
+}
 static int pc_class_compare_only(int cls) { const int nvar = pc_nw_num_variants(); return cls >= nvar * 4 && cls < nvar * 8; }
+// a launch whose longest column gene exceeds its variant's 64 x W columns runs strip-mined and needs the scratch slab
+static bool pc_launch_is_strip(int variant, int max_lb) { return variant >= 0 && max_lb > 64 * pc_nw_variant_w(variant); }
 
 static int apply_shard(pc_ctx* c, int rank, int world) {
     c->plan.valid = false;                             // a plan belongs to the shard it was made for
@@ -713,7 +724,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
             const int v = len_var[len];
             if (len_cls[len] < 0 || v < 0) continue;
             const int Wv = pc_nw_variant_w(v), Gv = ((int)len + Wv - 1) / Wv;
-            const int nseg = std::min(64 / Gv, 16);
+            const int nseg = std::max(1, std::min(64 / Gv, 16));        // (Gv > 64: a strip-mined gene, one row per wave)
             len_nseg[len] = (uint8_t)nseg;
             for (int r = 1; r < nseg; ++r) {
                 const int vr = pc_nw_choose_remainder((int)len, r, v);
@@ -989,7 +1000,12 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     size_t sbytes = 0;
     // percent-positives: systolic where the profile cell can run (it reads "positive" from a table), general kernel elsewhere
     auto launch_variant = [&](const Launch& l) { const int v = pc_class_variant(l.base); return (ppos && !pc_nw_ppos_systolic(v, l.max_lb)) ? pc_nw_ppos_variant(l.max_lb) : v; };
-    for (const Launch& l : launches) if (launch_variant(l) < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(l.max_lb));
+    auto uses_slab = [&](const Launch& l) { const int v = launch_variant(l); return v < 0 || pc_launch_is_strip(v, l.max_lb); };
+    for (const Launch& l : launches) {
+        const int v = launch_variant(l);
+        if (v < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(l.max_lb));
+        else if (pc_launch_is_strip(v, l.max_lb)) sbytes = std::max(sbytes, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
+    }
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     constexpr int kAux = pc_ctx::kAux;
     const int n_aux = std::min((int)launches.size(), c->n_streams) - 1;      // auxiliary streams this fill uses
@@ -1000,10 +1016,11 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         const int nt = (int)(l.end - l.begin);
         const int variant = launch_variant(l);
         // launches that use the one scratch slab stay in order on the caller's stream
-        hipStream_t ls = (variant < 0 || slot == 0) ? st : c->aux[slot - 1];
+        const bool slab = uses_slab(l);
+        hipStream_t ls = (slab || slot == 0) ? st : c->aux[slot - 1];
         int rc = pc_launch_nw(variant, c->dev, task_list + l.begin, nt, c->b_bucket_row.as<int32_t>(),
-                              nullptr /* result slot = position in the sorted list */, res, variant < 0 ? c->b_scratch.p : nullptr,
-                              variant < 0 ? c->b_scratch.cap : 0, l.max_lb, ppos, c->tie_rule, pc_class_compare_only(l.base), ls, l.mode);
+                              nullptr /* result slot = position in the sorted list */, res, slab ? c->b_scratch.p : nullptr,
+                              slab ? c->b_scratch.cap : 0, l.max_lb, ppos, c->tie_rule, pc_class_compare_only(l.base), ls, l.mode, c->max_gene_len);
         if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) % (n_aux + 1);
@@ -1370,6 +1387,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
             else if (!strcmp(set_force, "walker") && !counts) kernel = K_WALKER;
         }
     }
+    if (metric < PC_AAI) c->last_set_kernel = kernel;
     if ((metric == PC_GCS || metric == PC_JC) && kernel == K_SPARSE64) {
         rc = pc_launch_sparse64(metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC, d, c->shard, out, as_distance, condensed, st);
         if (rc != PC_OK) return rc;
@@ -1596,7 +1614,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         const int la = c->h_gene_len[a_gene[k]], lb = c->h_gene_len[b_gene[k]];
         if (la == 0 || lb == 0) { pc_set_error("pc_align_pairs: empty translation at %lld", (long long)k); return PC_ERR_DATA; }
         int v = forced == -2 ? pc_nw_choose_variant(lb) : forced;
-        if (v >= 0 && lb > 64 * pc_nw_variant_w(v)) { pc_set_error("pc_align_pairs: column gene of %d residues does not fit variant w=%d", lb, pc_nw_variant_w(v)); return PC_ERR_ARG; }
+        if (v >= 0 && lb > 64 * pc_nw_variant_w(v) && pc_nw_variant_w(v) < 32) { pc_set_error("pc_align_pairs: column gene of %d residues does not fit variant w=%d (strip-mined passes exist for w = 32, 48, 64)", lb, pc_nw_variant_w(v)); return PC_ERR_ARG; }
         cls[k] = pc_class_of(lb, v, c->h_gene_odd[b_gene[k]] != 0);                           // as pc_upload classes such column genes
         sums[k] = la + lb;
     }
@@ -1663,14 +1681,14 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         if (nt <= 0) continue;
         void* scratch = nullptr; size_t sbytes = 0;
         const int base = lc / PC_WAVE_MODES, v = pc_class_variant(base);
-        if (v < 0) {
-            sbytes = pc_nw_fallback_scratch_bytes(cls_maxlb[lc]);
+        if (v < 0 || pc_launch_is_strip(v, cls_maxlb[lc])) {
+            sbytes = v < 0 ? pc_nw_fallback_scratch_bytes(cls_maxlb[lc]) : pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu);
             if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return abi_rc(rc); }
-            scratch = c->b_scratch.p;
+            scratch = c->b_scratch.p; sbytes = c->b_scratch.cap;
         }
         rc = pc_launch_nw(v, c->dev, c->b_tasks.as<PcTask>() + cls_task_begin[lc], nt, c->b_bucket_row.as<int32_t>(),
                           c->b_bucket_dest.as<uint32_t>(), c->b_res.as<uint2>(), scratch, sbytes, cls_maxlb[lc], 0, c->tie_rule, pc_class_compare_only(base), st,
-                          lc % PC_WAVE_MODES);
+                          lc % PC_WAVE_MODES, c->max_gene_len);
         if (rc != PC_OK) { cleanup(); return rc; }
     }
     (void)hipEventRecord(c->ev[2], st);
@@ -1692,6 +1710,7 @@ extern "C" int pc_variant_width(int lb) {
 }
 
 extern "C" float pc_last_align_ms(const pc_ctx* c) { return c ? c->last_align_ms : -1.f; }
+extern "C" int pc_last_set_kernel(const pc_ctx* c) { return c ? c->last_set_kernel : -1; }
 
 extern "C" int pc_set_tie_rule(pc_ctx* c, int rule) {
     if (!c) { pc_set_error("pc_set_tie_rule: NULL context"); return PC_ERR_ARG; }

@@ -161,5 +161,8 @@ int pc_nw_task_mode(int lb, int rows, int variant);            // PC_MODE_* of a
 int pc_nw_small_modes_enabled();
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, int compare_only, hipStream_t st,
-                 int wave_mode = 0);   // wave_mode: PC_MODE_* -- workgroup shape of the launch's tasks
+                 int wave_mode = 0,    // wave_mode: PC_MODE_* -- workgroup shape of the launch's tasks
+                 int max_row_len = 65535);   // longest row sequence (sizes a strip-mined launch's boundary lines; see pc_nw_strip_scratch_bytes)
+size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu);    // scratch a strip-mined launch (max_lb > 64 x W of its variant) wants
+int pc_nw_strip_passes(int lb, int variant);                   // passes of 64 x W columns a column gene of lb residues takes on that variant (1: not strip-mined)
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

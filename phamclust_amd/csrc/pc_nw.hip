@@ -112,6 +112,9 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 #define PC_EXT2(W) PC_EXT2R(W, 2) PC_EXT2R(W, 3) PC_EXT2R(W, 4) PC_EXT2R(W, 5) PC_EXT2R(W, 6) PC_EXT2R(W, 7)
 PC_FOR_W2(PC_EXT2)
 PC_FOR_W1(PC_EXT1)
+#define PC_EXT_STRIP_R(W, INC, R) extern template int pc_strip_launch<W, R, INC> PC_STRIP_SIG;
+#define PC_EXT_STRIP(W, INC) PC_EXT_STRIP_R(W, INC, 2) PC_EXT_STRIP_R(W, INC, 3) PC_EXT_STRIP_R(W, INC, 4) PC_EXT_STRIP_R(W, INC, 5) PC_EXT_STRIP_R(W, INC, 6) PC_EXT_STRIP_R(W, INC, 7)
+PC_EXT_STRIP(32, false) PC_EXT_STRIP(48, false) PC_EXT_STRIP(64, false) PC_EXT_STRIP(24, true)
 
 // columns-per-lane of the compiled systolic variants
 static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 32, 48, 64};
@@ -129,8 +132,30 @@ int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants ||
 // sweep: the fill time is flat within 1 % over c0 = 0.3..1.0).  The nseg term stands for what short sequences pay
 // per alignment and per task (virtual row, pipeline fill, profile build).  Minimise cost per retired row over the
 // variants whose 64*W columns cover lb.  PC_CHOOSE_C0 / PC_CHOOSE_C1 override the constants for tuning runs.
+// Column genes beyond the widest variant's 4,096 columns run strip-mined (k_nw_strip): ceil(lb / 64 W) passes of a wide variant,
+// a pass costing a row step of that variant per row whatever its width -- the fewest step-instructions win (W = 32 / 48 / 64:
+// 2,048 / 3,072 / 4,096 columns per pass; penalties as below).  PC_STRIP=0 sends them to the general kernel as r01-r03 did.
+static bool strip_enabled() { static const bool off = getenv("PC_STRIP") && !atoi(getenv("PC_STRIP")); return !off; }
+int pc_nw_strip_passes(int lb, int variant) {
+    if (variant < 0 || variant >= g_num_variants || lb <= 0) return 0;
+    const int cols = 64 * g_variant_w[variant];
+    return (lb + cols - 1) / cols;
+}
+static int choose_strip_variant(int lb) {
+    if (!strip_enabled()) return -1;
+    int best = -1; double best_cost = 0;
+    for (int v = 0; v < g_num_variants; ++v) {
+        const int W = g_variant_w[v];
+        if (W < 32) continue;
+        const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : 1.04;
+        const double cost = (double)pc_nw_strip_passes(lb, v) * (W + 1.0) * pen;
+        if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
+    }
+    return best;
+}
 int pc_nw_choose_variant(int lb) {
     if (lb <= 0) return -1;
+    if (lb > 64 * PC_MAX_W) return choose_strip_variant(lb);
     int best = -1; double best_cost = 0;
     for (int v = 0; v < g_num_variants; ++v) {
         const int W = g_variant_w[v];
@@ -228,9 +253,11 @@ int pc_nw_class_waves(int variant, int lb, int compare_only) {
 }
 // Percent-positives (aai with ppos=True) needs the profile cell -- "positive" is a property of (row residue, column residue),
 // i.e. a table entry, not a residue compare: systolic where that cell can run, the general kernel elsewhere
+#define PC_STRIP_PPOS_MAX_LB 8191                     // the profile cell's statistics are 13-bit fields (PC_INC16_K)
 int pc_nw_ppos_systolic(int variant, int max_lb) {
     if (variant < 0 || variant >= g_num_variants || max_lb <= 0) return 0;
     const int W = g_variant_w[variant];
+    if (max_lb > 64 * W) return (W == PC_INC16_MAX_W && strip_enabled() && max_lb <= PC_STRIP_PPOS_MAX_LB) ? 1 : 0;   // strip-mined passes of W = 24
     return mode_inc16(W, (max_lb + W - 1) / W, 2) ? 1 : 0;
 }
 // ... and for a class whose own variant cannot (the wide ones, W >= 32, have no profile cell): the widest variant that has
@@ -255,6 +282,7 @@ int pc_nw_task_rows(int lb, int variant, int compare_only) {
     if (variant < 0 || variant >= g_num_variants || lb <= 0) return 64;       // general kernel: one pass of 64 rows
     const int W = g_variant_w[variant];
     const int G = (lb + W - 1) / W;
+    if (G > 64) return PC_STRIP_WAVES;                                        // strip-mined: one row per wave, pass after pass
     int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
     const int64_t steps = task_budget() / (W + 1);
     int64_t per_stream = steps / (lb + 1); if (per_stream < 1) per_stream = 1;
@@ -275,6 +303,7 @@ int pc_nw_task_mode(int lb, int rows, int variant) {
     static const int off = getenv("PC_SMALL_MODES") ? !atoi(getenv("PC_SMALL_MODES")) : 0;       // PC_SMALL_MODES=0: every task in its class's own workgroup shape
     if (off || variant < 0 || variant >= g_num_variants || lb <= 0) return PC_MODE_CLASS;
     const int W = g_variant_w[variant], G = (lb + W - 1) / W;
+    if (G > 64) return PC_MODE_CLASS;                                         // strip-mined tasks have one shape
     int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
     return rows <= nseg ? PC_MODE_ONE_WAVE : rows <= 2 * nseg ? PC_MODE_TWO_WAVES : PC_MODE_CLASS;
 }
@@ -315,6 +344,36 @@ static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, cons
     }
 }
 
+// Scratch of a strip-mined launch: one boundary line of (longest row + 2) 16-byte entries per wave of every resident workgroup
+static size_t strip_bytes_per_block(int max_row_len) { return (size_t)PC_STRIP_WAVES * ((size_t)max_row_len + 2) * sizeof(uint4); }
+size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu) {
+    const size_t per = strip_bytes_per_block(max_row_len);
+    size_t blocks = (size_t)2 * (n_cu > 0 ? n_cu : 256);
+    const size_t budget = (size_t)1 << 30;
+    if (blocks * per > budget) blocks = std::max<size_t>(budget / per, 8);
+    return blocks * per;
+}
+template <int W, bool INC16>
+static int launch_strip(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res,
+                        void* scratch, size_t scratch_bytes, int max_row_len, int ppos, int rule, hipStream_t st) {
+    const size_t per = strip_bytes_per_block(max_row_len);
+    size_t blocks = scratch ? scratch_bytes / per : 0;
+    if (blocks == 0) { pc_set_error("k_nw_strip<%d>: needs %zu bytes of scratch per workgroup", W, per); return PC_ERR_ARG; }
+    if (blocks > (size_t)ntasks) blocks = (size_t)ntasks;
+    if (blocks > 4096) blocks = 4096;
+    const size_t lines = INC16 ? (size_t)2 * ((pc_prof_rows(true) + 1) / 2) : (size_t)pc_prof_rows(false);
+    const size_t lds = (size_t)(144 + PC_STRIP_WAVES * pc_strip_wave_lds_dwords()) * 4 + lines * pc_prof_row_dwords(W, INC16) * 256;
+    hipError_t e = hipSuccess;
+    switch (rule) {
+#define PC_STRIP_CASE(R) case R: e = (hipError_t)pc_strip_launch<W, R, INC16>((unsigned)blocks, lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, (uint4*)scratch, (unsigned)(max_row_len + 2)); break;
+    PC_STRIP_CASE(0) PC_STRIP_CASE(1) PC_STRIP_CASE(2) PC_STRIP_CASE(3) PC_STRIP_CASE(4) PC_STRIP_CASE(5) PC_STRIP_CASE(6) PC_STRIP_CASE(7)
+#undef PC_STRIP_CASE
+    default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
+    }
+    if (e != hipSuccess) { pc_set_error("k_nw_strip<%d,%d> launch: %s", W, rule, hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
 size_t pc_nw_fallback_scratch_bytes(int max_lb) {
     size_t per_block = (size_t)64 * (size_t)max_lb * sizeof(int4);
     size_t budget = (size_t)2 << 30;
@@ -326,13 +385,19 @@ size_t pc_nw_fallback_scratch_bytes(int max_lb) {
 
 int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int rule, int compare_only, hipStream_t st,
-                 int wave_mode) {
+                 int wave_mode, int max_row_len) {
     if (ntasks <= 0) return PC_OK;
     if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_launch_nw: tie rule %d out of range", rule); return PC_ERR_ARG; }
     if (variant >= 0 && ppos && !pc_nw_ppos_systolic(variant, max_lb)) { pc_set_error("pc_launch_nw: percent-positives cannot run on variant %d for %d columns", variant, max_lb); return PC_ERR_ARG; }
     if (variant >= 0) {
-        if (variant >= g_num_variants || max_lb > 64 * g_variant_w[variant]) {
-            pc_set_error("pc_launch_nw: variant %d cannot take %d columns", variant, max_lb); return PC_ERR_ARG;
+        if (variant >= g_num_variants) { pc_set_error("pc_launch_nw: no variant %d", variant); return PC_ERR_ARG; }
+        if (max_lb > 64 * g_variant_w[variant]) {                                // strip-mined passes (k_nw_strip)
+            const int W = g_variant_w[variant];
+            if (ppos && W == PC_INC16_MAX_W) return launch_strip<PC_INC16_MAX_W, true>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 1, rule, st);
+            if (!ppos && W == 32) return launch_strip<32, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);
+            if (!ppos && W == 48) return launch_strip<48, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);
+            if (!ppos && W == 64) return launch_strip<64, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);
+            pc_set_error("pc_launch_nw: variant %d (w = %d) cannot take %d columns", variant, W, max_lb); return PC_ERR_ARG;
         }
         switch (g_variant_w[variant]) {
 #define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, ppos ? 2 : ((compare_only != 0 || wave_mode == PC_MODE_ONE_WAVE) ? 1 : 0), rule, st, wave_mode);

@@ -9,3 +9,6 @@
 #define PC_INST2(W) PC_INST1(W) template int pc_systolic_launch<W, PC_RULE_A, true> PC_SYSTOLIC_SIG; template int pc_systolic_launch<W, PC_RULE_B, true> PC_SYSTOLIC_SIG;
 PC_FOR_W2(PC_INST2)
 PC_FOR_W1(PC_INST1)
+// the strip-mined kernel (column genes beyond 64 x W columns): the three wide variants, and W = 24 with the profile cell (percent-positives)
+#define PC_INST_STRIP(W, INC) template int pc_strip_launch<W, PC_RULE_A, INC> PC_STRIP_SIG; template int pc_strip_launch<W, PC_RULE_B, INC> PC_STRIP_SIG;
+PC_INST_STRIP(32, false) PC_INST_STRIP(48, false) PC_INST_STRIP(64, false) PC_INST_STRIP(24, true)

@@ -559,6 +559,289 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
 }
 
 
+
+// ---------------------------------------------------------------------------------
+// Strip-mined passes for column genes LONGER than a variant's 64 x W columns (r04; the reference's aligner has no length cliff,
+// metrics.py:160-175 -- r01-r03 sent such genes to a one-lane-per-alignment kernel at ~1/30 of the systolic rate).
+//
+// The column gene is cut into passes of 64 x W columns.  A wave aligns ONE row sequence per task against pass after pass: in
+// every pass but the last, the lane holding the pass's last column writes what its right-hand neighbour would have received --
+// (Ho, E) of that column, both 64-bit words, statistics included -- to a line in HBM, one 16-byte entry per row step; in the next
+// pass the head lane takes its left-hand boundary from that line instead of the constants -22 / -inf / 0.  The virtual row -1 is
+// an ordinary stream entry, so its boundary travels the same way, and the anti-diagonal bias and the base of the alignment ride
+// inside the values.  An entry is written at step t for stream position t - 63 and read back at position t: a pass never
+// overwrites what it has yet to read, so ONE line per wave serves all passes.  The line is staged 32 entries at a time by the
+// idle half of the refill (agent-scope loads: the same wave wrote the line in the pass before).
+// One alignment per stream: nothing follows it, so the base never steps (an alignment against 65,535 columns spans 3.4 M in
+// `hi`, more than PC_BASE_STEP), and the column state is re-initialised in every pass -- what the lanes hold from the previous
+// pass belongs to the SAME alignment and would not lose the maxima.
+// Persistent grid (pc_launch_nw sizes it by the scratch it has): a workgroup of 4 waves takes every gridDim-th task, 4 rows each;
+// all waves meet at two barriers per pass (the profile of the pass's columns is shared).
+// Limits: statistics are 16-bit fields (compare cell: la, lb <= 65,535) or 13-bit ones (profile cell, used for percent-positives:
+// lb <= 8,191).
+// ---------------------------------------------------------------------------------
+#define PC_STRIP_WAVES 4
+#define PC_STRIP_BND 64                                            // boundary entries a wave keeps staged (two refill windows)
+__host__ __device__ constexpr int pc_strip_wave_lds_dwords() { return 16 + PC_WIN + 4 * PC_STRIP_BND; }
+
+template <int W, int RULE, bool INC16>
+__global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_strip(PcDev d, const PcTask* __restrict__ tasks, int ntasks,
+                                                                          const int32_t* __restrict__ bucket_row,
+                                                                          const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res, int ppos,
+                                                                          uint4* __restrict__ spill, unsigned spill_stride) {
+    constexpr int ND = (W + 3) / 4;
+    constexpr int NDM = INC16 ? (W + 1) / 2 : 0;
+    constexpr int RS = pc_prof_row_dwords(W, INC16);
+    constexpr int ROWS = pc_prof_rows(INC16);
+    constexpr bool BYTE_OFF = ((INC16 ? (ROWS + 1) / 2 : ROWS) * RS * 256) < 65536;
+    static_assert(!INC16 || BYTE_OFF, "profile-cell tables must keep byte offsets");
+    constexpr int COLS = 64 * W;                                   // columns of a full pass
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    int8_t (*tab)[24] = (int8_t(*)[24])smem;
+    for (int i = threadIdx.x; i < 576; i += 64 * PC_STRIP_WAVES) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
+    // the layout of the widest lanes-per-segment bucket, whatever a pass's own width: one (profile cell: two half) table(s) of 64 lanes
+    constexpr int Gl = INC16 ? 32 : 64;
+    constexpr uint32_t half_dw = INC16 ? (uint32_t)(((ROWS + 1) / 2) * RS * 64) : 0u;
+    auto row_part = [&](uint32_t r) { return (INC16 ? ((r >> 1) * (uint32_t)(RS * 64) + (r & 1u) * 32u) : r * (uint32_t)(RS * 64)) * (BYTE_OFF ? 4u : 1u); };
+    uint32_t* wreg = smem + 144 + wv * pc_strip_wave_lds_dwords();
+    uint32_t* ring = wreg + 16;                                    // [PC_WIN] staged stream entries
+    uint32_t* bnd = ring + PC_WIN;                                 // [PC_STRIP_BND][4] staged boundary entries (Ho.hi, Ho.lo, E.hi, E.lo)
+    uint32_t* prof = smem + 144 + PC_STRIP_WAVES * pc_strip_wave_lds_dwords();
+    const uint32_t kcol = (uint32_t)(lane < Gl ? lane : lane - Gl) + (lane < Gl ? 0u : half_dw);
+    uint4* const line = spill + ((size_t)blockIdx.x * PC_STRIP_WAVES + (size_t)wv) * spill_stride;
+    using TG = PcTag<RULE>;
+    const uint32_t K = 0x10000u;
+    const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + kcol * 4u;
+    const uint32_t v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0;
+
+#pragma unroll 1
+    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const PcTask tk = tasks[task];
+        const int lb_all = d.gene_len[tk.gene];
+        const uint8_t* __restrict__ bp_all = d.codes + d.gene_off[tk.gene];
+        const int npass = (lb_all + COLS - 1) / COLS;
+        const int R = tk.end - tk.begin;                           // normally <= PC_STRIP_WAVES rows: one round of one row per wave
+#pragma unroll 1
+        for (int r0 = 0; r0 < R; r0 += PC_STRIP_WAVES) {
+        const int my_row = r0 + wv;
+        const bool have_row = my_row < R;
+        int la = 0; const uint8_t* ap = d.codes;
+        if (have_row) { const int ga = bucket_row[tk.begin + my_row]; la = d.gene_len[ga]; ap = d.codes + d.gene_off[ga]; }
+        const int seg_len = have_row ? la + 1 : 0;                 // the virtual row -1, then the la residues
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) {
+            const int col0 = pass * COLS, lb = min(COLS, lb_all - col0);
+            const uint8_t* __restrict__ bp = bp_all + col0;
+            const int G = (lb + W - 1) / W;                        // lanes of this pass (64 in every pass but the last)
+            const bool in_seg = lane < G, is_head = lane == 0;
+            const int k_out = (lb - 1) / W, c_out = (lb - 1) - k_out * W;
+            const bool last_pass = pass == npass - 1;
+            const bool is_out = last_pass && lane == k_out;
+            uint32_t bc[ND];
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = lane * W + q * 4 + e;
+                    const uint32_t code = (q * 4 + e < W && in_seg && j < lb) ? (uint32_t)bp[j] : (uint32_t)PC_PADCODE;
+                    v |= code << (8 * e);
+                }
+                bc[q] = v;
+            }
+            __syncthreads();                                       // score table visible; every wave is done with the previous pass's profile
+            if (in_seg) {
+#pragma unroll 1
+                for (int r = wv; r < ROWS; r += PC_STRIP_WAVES) {
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = q * 4 + e;
+                            if (c < W) v |= (uint32_t)(uint8_t)tab[min(r, 23)][min((int)((bc[q] >> (8 * e)) & 0xffu), 23)] << (8 * e);
+                        }
+                        prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + q * 64 + kcol] = v;
+                    }
+                    if constexpr (INC16) {
+#pragma unroll
+                        for (int q = 0; q < NDM; ++q) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int c = q * 2 + e;
+                                const int bcode = (int)((bc[c >> 2] >> (8 * (c & 3))) & 0xffu);
+                                if (c < W) v |= (PC_INC16_K + (uint32_t)((r < 24 && bcode == r) || (ppos && (int)tab[min(r, 23)][min(bcode, 23)] > 48 + (PcTag<RULE>::tD - PcTag<RULE>::tOF)))) << (16 * e);
+                            }
+                            prof[row_part(r) / (BYTE_OFF ? 4u : 1u) + (ND + q) * 64 + kcol] = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                       // profile of this pass complete
+            const int T = have_row ? seg_len + G - 1 : 0;
+            double Hou[W], Fu[W];
+#pragma unroll
+            for (int c = 0; c < W; ++c) { Hou[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u); Fu[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tF), 0u); }
+            double o_E = pc_pack((uint32_t)(PC_NEG4 + TG::tE), 0u);
+            double p_HoL = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u);
+            uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
+            const int hl = lane & (PC_WIN - 1);
+            auto refill = [&](int base) {
+                pc_wave_lds_sync();
+                const uint32_t p = (uint32_t)base + (uint32_t)hl;
+                if (lane < PC_WIN) {                                // the stream entries of positions base .. base + 31
+                    uint32_t entry = 0;
+                    if (p < (uint32_t)seg_len) {
+                        const int i = (int)p - 1;
+                        if (i < 0) entry = PCF_RESET;
+                        else {
+                            const uint32_t code = ap[i];
+                            entry = code | (i == la - 1 ? PCF_LAST : 0) | (row_part(min(code, (uint32_t)(ROWS - 1))) << 16);
+                        }
+                    }
+                    ring[hl] = entry;
+                } else if (pass > 0 && p < (uint32_t)seg_len) {     // ... and the head's boundary for the same positions, from the pass before
+                    const unsigned long long* src = (const unsigned long long*)(line + p);
+                    const unsigned long long x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(uint4*)&bnd[(p & (PC_STRIP_BND - 1)) * 4] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+                }
+                pc_wave_lds_sync();
+            };
+            auto row_addr = [&](uint32_t entry) -> uint32_t {
+                if constexpr (BYTE_OFF) {
+                    uint32_t addr;
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(entry), "v"(prof_lane));
+                    return addr;
+                } else return (entry >> 14) + prof_lane;
+            };
+            if (T > 0) {                                            // (wave-uniform: a wave without a row only keeps the barriers)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my own stores of the previous pass have left the wave
+            refill(0);
+            uint32_t a = is_head ? ring[0] : 0u;
+            uint32_t e_nxt = ring[1];
+            uint32_t e_b = 0;
+            uint32_t pw[ND], pm[INC16 ? NDM : 1];
+            {
+                pc_lds_u32* r0 = (pc_lds_u32*)(size_t)row_addr(a);
+#pragma unroll
+                for (int q = 0; q < ND; ++q) pw[q] = r0[q * 64];
+                if constexpr (INC16) {
+#pragma unroll
+                    for (int q = 0; q < NDM; ++q) pm[q] = r0[(ND + q) * 64];
+                } else pm[0] = 0;
+            }
+            const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out), headoutm = headm | outm;
+            const uint32_t v_base_step = PC_BASE_STEP;
+            auto step = [&](int t, const bool even, uint32_t a, uint32_t& a_nxt) {
+                if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
+                // the head lane's left-hand boundary of this row: the constants of column -1 in the first pass, else what the
+                // previous pass left for stream position t (every lane reads the one entry: a broadcast)
+                uint32_t bHh = v_hb, bHl = 0u, bEh = v_nege, bEl = 0u;
+                if (pass > 0) { const uint4 b = *(const uint4*)&bnd[(t & (PC_STRIP_BND - 1)) * 4]; bHh = b.x; bHl = b.y; bEh = b.z; bEl = b.w; }
+                uint32_t HoL_hi, HoL_lo, EL_hi, EL_lo, D0_hi, D0_lo;
+                unsigned long long anym;
+                if constexpr (INC16) {
+                    asm volatile(
+                        "s_nop 1\n\t"
+                        "s_mov_b64 vcc, %[hm]\n\t"
+                        "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[Hh], %[Hwh], %[bHh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[Eh], %[oEh], %[bEh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[Hl], %[Hwl], %[bHl], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[El], %[oEl], %[bEl], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cmp_ne_u32_sdwa %[anym], %[a], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+                        "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                        "v_add_u32_sdwa %[D0l], %[pm0], %[Hodl] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                        "s_and_b64 %[anym], %[anym], %[hom]\n\t"
+                        : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
+                          [D0l] "=&v"(D0_lo), [anym] "=&s"(anym)
+                        : [hm] "s"(headm), [hom] "s"(headoutm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [bHh] "v"(bHh), [oEh] "v"(pc_hi(o_E)), [bEh] "v"(bEh),
+                          [Hwl] "v"(pc_lo(Hou[W - 1])), [bHl] "v"(bHl), [oEl] "v"(pc_lo(o_E)), [bEl] "v"(bEl), [zero] "v"(v_zero), [pw0] "v"(pw[0]), [pm0] "v"(pm[0]),
+                          [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
+                        : "vcc", "scc");
+                } else {
+                    unsigned long long c2;
+                    asm volatile(
+                        "s_nop 1\n\t"
+                        "s_mov_b64 vcc, %[hm]\n\t"
+                        "v_cmp_eq_u32_sdwa %[c2], %[a], %[bc0] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                        "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[Hh], %[Hwh], %[bHh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[Eh], %[oEh], %[bEh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[Hl], %[Hwl], %[bHl], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32_dpp %[El], %[oEl], %[bEl], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cmp_ne_u32_sdwa %[anym], %[a], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+                        "v_add_u32_sdwa %[D0h], %[pw0], %[Hodh] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                        "v_addc_co_u32 %[D0l], %[c2], %[K], %[Hodl], %[c2]\n\t"
+                        "s_and_b64 %[anym], %[anym], %[hom]\n\t"
+                        : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
+                          [D0l] "=&v"(D0_lo), [anym] "=&s"(anym), [c2] "=&s"(c2)
+                        : [hm] "s"(headm), [hom] "s"(headoutm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [bHh] "v"(bHh), [oEh] "v"(pc_hi(o_E)), [bEh] "v"(bEh),
+                          [Hwl] "v"(pc_lo(Hou[W - 1])), [bHl] "v"(bHl), [oEl] "v"(pc_lo(o_E)), [bEl] "v"(bEl), [zero] "v"(v_zero), [K] "v"(K), [bc0] "v"(bc[0]), [pw0] "v"(pw[0]),
+                          [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
+                        : "vcc", "scc");
+                }
+                pc_lds_u32* nxt = (pc_lds_u32*)(size_t)row_addr(a_nxt);
+                if (even) {
+                    const uint2 e2 = *(const uint2*)&ring[(t + 2) & (PC_WIN - 1)];
+                    e_nxt = e2.x; e_b = e2.y;
+                } else e_nxt = e_b;
+                unsigned long long rstm = 0, lastm = 0;
+                asm volatile("" : "+s"(anym));
+                if (anym != 0)
+                    asm volatile("v_cmp_lt_u32_sdwa %0, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                                 "v_cmp_eq_u32_sdwa %1, %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+                                 "s_and_b64 %0, %0, %4\n\t"
+                                 "s_and_b64 %1, %1, %5"
+                                 : "=&s"(rstm), "=&s"(lastm) : "v"(K), "v"(a), "s"(headm), "s"(outm) : "scc");
+                if (rstm != 0 && pass == 0) {                       // the alignment starts (first pass only: later passes read the virtual row's boundary)
+                    uint32_t inc;
+                    asm volatile("v_cndmask_b32 %0, %4, %5, %6\n\tv_add_u32 %1, %1, %0\n\tv_add_u32 %2, %2, %0\n\tv_cndmask_b32 %3, %3, %2, %6"
+                                 : "=&v"(inc), "+v"(v_hb), "+v"(v_h00), "+v"(HoL_hi) : "v"(v_zero), "v"(v_base_step), "s"(rstm));
+                }
+                const double HoL = pc_pack(HoL_hi, HoL_lo);
+                p_HoL = HoL;
+                PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
+                if (!last_pass) {                                   // what lane 64 would have received for this row: the next pass's boundary
+                    const int p = t - 63;
+                    if (lane == 63 && p >= 0 && p < seg_len)
+                        line[p] = make_uint4(pc_hi(Hou[W - 1]), pc_lo(Hou[W - 1]), pc_hi(o_E), pc_lo(o_E));
+                }
+                asm volatile("" : "+s"(lastm));
+                if (lastm != 0) {
+                    asm volatile("" ::: "memory");
+                    if ((a & PCF_LAST) && is_out) {
+                        const uint32_t st = PcPick<W, 0>::get(Hou, c_out);
+                        const uint32_t n_ident = INC16 ? (st & (PC_INC16_K - 1)) : (st & 0xffffu), n_diag = INC16 ? (st >> 13) : (st >> 16);
+                        res[bucket_dest ? bucket_dest[tk.begin + my_row] : (uint32_t)(tk.begin + my_row)] = make_uint2(n_ident, (uint32_t)la + (uint32_t)lb_all - n_diag);
+                    }
+                }
+            };
+            uint32_t a2 = 0;
+#pragma unroll 1
+            for (int t = 0; t < T; t += 2) {
+                step(t, true, a, a2);
+                step(t + 1, false, a2, a);
+            }
+            }
+        }
+        }
+        __syncthreads();                                           // the next task rebuilds the profile
+    }
+}
+
+template <int W, int RULE, bool INC16>
+int pc_strip_launch(unsigned nblocks, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks, int ntasks,
+                    const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos, uint4* spill, unsigned spill_stride) {
+    hipLaunchKernelGGL((k_nw_strip<W, RULE, INC16>), dim3(nblocks), dim3(64 * PC_STRIP_WAVES), lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, spill, spill_stride);
+    return (int)hipGetLastError();
+}
+#define PC_STRIP_SIG (unsigned, size_t, hipStream_t, const PcDev&, const PcTask*, int, const int32_t*, const uint32_t*, uint2*, int, uint4*, unsigned)
+
 // One launch of k_nw_systolic<W, RULE, INC16>; returns the hipError_t of the launch.  The only thing a translation unit
 // needs to instantiate (explicitly, in pc_nw_rules.hip; implicitly for rules 0 and 1 in pc_nw.hip).
 // (hipExtLaunchKernel's hipExtAnyOrderLaunch -- launches of one queue without the AQL barrier bit, so that a launch need not wait

@@ -242,11 +242,11 @@ def local_device():
 def ensure_process_group():
     """Join the job's process group if the launcher started more than one rank and nothing has joined it yet.
     Must run before this process's first GPU call under nccl (RCCL binds the device at init).  Returns (rank, world)."""
-    import torch
-    import torch.distributed as dist
     rank, _, world = env_world()
     if world <= 1:
-        return 0, 1
+        return 0, 1                                            # (one rank: torch is not even imported)
+    import torch
+    import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -48,7 +48,7 @@ EXPORTS = ["pc_version", "pc_test_hooks", "pc_last_error", "pc_ctx_create", "pc_
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs",
            "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev", "pc_upload_sets", "pc_upload_residues", "pc_set_plan_budget", "pc_chunk_plan",
-           "pc_variant_width"]
+           "pc_variant_width", "pc_last_set_kernel"]
 NEEDS_RESIDUES = ("aai", "peq", "aai_ppos")
 
 _lib = None
@@ -65,10 +65,14 @@ def load():
     # torch ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both open
     # the GPU.  Importing torch first makes our library bind to the runtime torch uses, so
     # torch tensors, streams and torch.distributed (RCCL) share one device context with it.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # PHAMCLUST_NO_TORCH=1 (the single-rank CLI sets it) skips that import -- ~1.5 s, a minute or two on a machine that pages torch
+    # in for the first time -- for processes that will never import torch: the library then binds to the system's HIP runtime.
+    import sys
+    if os.environ.get("PHAMCLUST_NO_TORCH") != "1" or "torch" in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as exc:
@@ -106,6 +110,7 @@ def load():
     L.pc_last_align_ms.restype = ctypes.c_float
     L.pc_shard_table.argtypes = [vp, _i32p, _i64p]
     L.pc_target_costs.argtypes = [vp, _u64p]
+    L.pc_last_set_kernel.argtypes = [vp]
     L.pc_set_tie_rule.argtypes = [vp, ctypes.c_int]
     L.pc_get_tie_rule.argtypes = [vp]
     _lib = L
@@ -394,6 +399,12 @@ class Context:
 
     def last_align_ms(self):
         return float(self._lib.pc_last_align_ms(self._h))
+
+    SET_KERNELS = {0: "popc", 1: "sparse", 2: "sparse64", 3: "walker", -1: None}
+
+    def last_set_kernel(self):
+        """Kernel family the selector gave the last gcs / jc / pocp / af fill (the names PC_SET_KERNEL takes)."""
+        return self.SET_KERNELS[int(self._lib.pc_last_set_kernel(self._h))]
 
     @staticmethod
     def chunk_plan(counts, max_per_chunk):

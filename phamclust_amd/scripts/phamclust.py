@@ -27,12 +27,20 @@ from phamclust_amd.clustering import hierarchical_clustering
 from phamclust_amd.genome import Genome
 from phamclust_amd.heatmap import CSS_COLORS, draw_heatmap
 from phamclust_amd.matrix import matrix_de_novo, matrix_from_squareform, matrix_to_adjacency, matrix_to_squareform
-from phamclust_amd.pack import load_tsv_genomes
+from phamclust_amd.pack import load_tsv_genomes, packed_behind
+from phamclust_amd import startup
 
 LOG_STR_FMT = "phamclust: %(asctime)s.%(msecs)03d: %(levelname)s: %(message)s"
 LOG_TIME_FMT = "%H:%M:%S"
 FASTA_SUFFIXES = {".fasta", ".faa", ".fa"}
 log = logging.getLogger()
+TIMELINE = None                    # startup.Timeline of this run (main() makes it; library callers of phamclust() run without)
+_PRELOADED = {}                    # infile -> genomes the CLI already loaded for its --gpus estimate
+
+
+def _mark(name):
+    if TIMELINE is not None:
+        TIMELINE.mark(name)
 
 
 # ---- input ---------------------------------------------------------------------------------
@@ -124,9 +132,10 @@ class _Run:
         if is_genome_dir:
             self.genomes = sorted(load_genomes_from_fasta_dir(infile), key=lambda g: g.name)
         else:
-            self.genomes = load_genomes(infile)
+            self.genomes = _PRELOADED.pop(str(infile), None) or load_genomes(infile)
         self.by_name = {g.name: g for g in self.genomes}
         log.info(f"loaded {len(self.genomes)} genomes in {time.perf_counter() - t0:.3f} s")
+        _mark("load_genomes")
         if self.rank != 0:                    # the other ranks only need the genomes: rank 0 owns the output tree
             return
         digest = _hash_genomes(self.genomes)
@@ -174,6 +183,10 @@ class _Run:
             log.info(line)
             if self.metric in _metrics.PARITY_NOTE:          # say it wherever these numbers leave the program
                 log.info(f"parity: {_metrics.parity_note(self.metric)}")
+            if TIMELINE is not None:                         # the matrix stage, split (matrix_de_novo's own clocks)
+                TIMELINE.stamps += [("pack", st.get("pack_s", 0.0)), ("process_group_and_context", max(0.0, wall - st.get("pack_s", 0.0) - st.get("upload_s", 0.0) - st.get("fill_s", 0.0))),
+                                    ("upload", st.get("upload_s", 0.0)), ("fill_exchange_d2h", st.get("fill_s", 0.0))]
+                TIMELINE._last = time.time()
             matrix_to_squareform(matrix, cached, lower_triangle=True)
         if not matrix.is_distance:
             matrix.invert()
@@ -298,12 +311,31 @@ def main(argv=None):
         kind = "genome directory" if args.genome_dir else "input TSV"
         print(f"{kind} '{args.infile}' does not exist")
         sys.exit(1)
+    global TIMELINE
+    TIMELINE = startup.Timeline()
+    TIMELINE.mark("imports")
     rank, _, world = distributed.env_world()
+    gpus_note = None
     if args.gpus > 1 and world == 1:
-        # `--gpus N`: re-run this command line as N ranks, one per GPU, under the launcher -- as a child process,
-        # before this process has made a single GPU call
-        passed = list(sys.argv[1:] if argv is None else argv)
-        sys.exit(distributed.launch_ranks(args.gpus, "phamclust_amd", [str(x) for x in passed]))
+        # `--gpus N`: N ranks cost seconds to start (an interpreter, a torch import and a process-group init each); the
+        # reference clamps its workers to the work too (matrix.py:460-462).  Load the genomes here -- host code only, no GPU
+        # call -- estimate the fill, and start the ranks only when they can win that back.
+        n_ranks = args.gpus
+        if not args.genome_dir:
+            genomes = load_genomes(args.infile)
+            TIMELINE.mark("load_genomes_for_estimate")
+            packed = packed_behind(genomes)
+            if packed is not None:
+                n_ranks, gpus_note = startup.choose_gpus(args.gpus, packed, args.metric)
+                _PRELOADED[str(args.infile)] = genomes
+        if n_ranks > 1:
+            # re-run this command line as N ranks, one per GPU, under the launcher -- as a child process, before this
+            # process has made a single GPU call
+            passed = list(sys.argv[1:] if argv is None else argv)
+            sys.exit(distributed.launch_ranks(n_ranks, "phamclust_amd", [str(x) for x in passed],
+                                              env={"PHAMCLUST_T0": repr(TIMELINE.t_launch), "PHAMCLUST_FORCE_GPUS": "1"}))
+    if world == 1:
+        os.environ.setdefault("PHAMCLUST_NO_TORCH", "1")           # one rank: nothing needs torch (hip.load() then skips its import)
     if args.device is not None and world == 1:
         os.environ["PHAMCLUST_DEVICE"] = str(args.device)           # matrix.default_device reads it when the context is made
     args.outdir.mkdir(parents=True, exist_ok=True)
@@ -313,6 +345,8 @@ def main(argv=None):
         log.addHandler(logging.StreamHandler(sys.stdout))
     else:                                     # rank 0 owns the log file and the output tree
         logging.basicConfig(stream=sys.stderr, format=f"phamclust[rank {rank}]: %(levelname)s: %(message)s", level=logging.WARNING, force=True)
+    if gpus_note and rank == 0:
+        log.info(f"--gpus {args.gpus}: {gpus_note}")
     as_distance = lambda similarity: round(1.0 - similarity, 6)          # noqa: E731
     try:
         phamclust(infile=args.infile, outdir=args.outdir, is_genome_dir=args.genome_dir, metric=args.metric,
@@ -322,6 +356,9 @@ def main(argv=None):
                   no_sub=args.no_sub, colors=_colors(args.heatmap_colors), midpoint=round(args.heatmap_midpoint, 6),
                   cpus=args.threads, rm_tmp=args.remove_tmp, debug=args.debug)
     finally:
+        if rank == 0:
+            TIMELINE.mark("clustering_and_outputs")
+            log.info(TIMELINE.line())
         if world > 1:
             import torch.distributed as dist
             if dist.is_initialized():

@@ -1,0 +1,105 @@
+"""What ``--gpus N`` costs before the first pair is filled, and when it is not worth paying.
+
+The reference pays its worker-pool start-up inside ``matrix_de_novo`` (matrix.py:471-472) and clamps the workers to the work
+(matrix.py:460-462: never more CPUs than genome pairs).  Here ``--gpus N`` means one process per GPU under
+``torch.distributed.run``: one interpreter, one torch import and one RCCL initialisation PER RANK before any rank fills a pair --
+seconds, against a fill that takes 0.6 s for 5,000 genomes on one GPU.  So the CLI estimates the fill from the loaded genomes
+before it touches a GPU, compares what N ranks would save with what starting them costs (measured:
+``profiles/r04/launch_cost.txt``), and stays on one GPU when the job loses; the log says why.
+"""
+
+import json
+import os
+import time
+
+import numpy as np
+
+# Measured on the one-GPU box with the launcher and the gloo rehearsal transport (tools/launch_cost.py ->
+# profiles/r04/launch_cost.txt): seconds from `phamclust --gpus N` being started to the ranks' first GPU call, minus the same
+# for `--gpus 1` -- the launcher process, N interpreters importing torch, the process group.  PHAMCLUST_LAUNCH_COST_S overrides.
+LAUNCH_COST_S = 6.0
+# one GPU, sustained (bench.py / profiles/): DP cells per second of the alignment kernels, genome pairs per second of the
+# set-metric kernels, bytes per second of the D2H copy into pinned memory
+CELLS_PER_S = 3.3e12
+SET_PAIRS_PER_S = 5.0e10
+D2H_BYTES_PER_S = 5.0e10
+
+
+def process_start_time():
+    """Epoch seconds at which this PROCESS was created (the interpreter's own start-up included)."""
+    try:
+        import psutil
+        return psutil.Process().create_time()
+    except Exception:                                          # noqa: BLE001
+        return time.time()
+
+
+class Timeline:
+    """Stage stamps of one CLI run, logged as one parseable line: ``timing: {json}`` (tools/launch_cost.py reads it)."""
+
+    def __init__(self):
+        self.t_process = process_start_time()
+        self.t_launch = float(os.environ.get("PHAMCLUST_T0", self.t_process))      # when the user's command started (the parent, under --gpus N)
+        self.stamps = [("interpreter_start", self.t_process - self.t_launch)]
+        self._last = self.t_process
+
+    def mark(self, name):
+        now = time.time()
+        self.stamps.append((name, now - self._last))
+        self._last = now
+
+    def as_dict(self):
+        d = {name: round(seconds, 4) for name, seconds in self.stamps}
+        d["total_since_command_start"] = round(time.time() - self.t_launch, 4)
+        return d
+
+    def line(self):
+        return "timing: " + json.dumps(self.as_dict())
+
+
+def launch_cost_seconds(n_gpus):
+    """Fixed cost of running as ``n_gpus`` ranks instead of in this process."""
+    if n_gpus <= 1:
+        return 0.0
+    env = os.environ.get("PHAMCLUST_LAUNCH_COST_S")
+    return float(env) if env else LAUNCH_COST_S
+
+
+def alignment_cells(packed):
+    """Upper estimate of the DP cells an aai / peq fill aligns: every gene against every gene of the same pham in another
+    genome, sum of la * lb = (L_p^2 - sum_g L_gp^2) / 2 over the phams (metrics.py:203-224; the anchor rule only drops
+    paralog-against-paralog repeats).  Host arithmetic on the packed arrays -- no GPU."""
+    lens = np.diff(packed.seq_off).astype(np.float64)
+    pham = np.asarray(packed.gene_pham, dtype=np.int64)
+    genome = np.repeat(np.arange(packed.n_genomes, dtype=np.int64), np.diff(packed.gene_off))
+    per_pham = np.bincount(pham, weights=lens, minlength=packed.n_phams)
+    key = genome * packed.n_phams + pham
+    _, inverse = np.unique(key, return_inverse=True)
+    per_entry = np.bincount(inverse, weights=lens)
+    return float((np.square(per_pham).sum() - np.square(per_entry).sum()) / 2.0)
+
+
+def estimate_fill_seconds(packed, metric):
+    """Seconds ONE GPU needs for the whole matrix of ``metric`` (kernels + D2H), from the genomes alone."""
+    pairs = packed.n_genomes * (packed.n_genomes - 1) / 2.0
+    seconds = pairs * 8.0 / D2H_BYTES_PER_S + pairs / SET_PAIRS_PER_S
+    if metric in ("aai", "peq"):
+        seconds += alignment_cells(packed) / CELLS_PER_S
+    return seconds
+
+
+def choose_gpus(requested, packed, metric):
+    """How many ranks to start for ``--gpus requested``: (n, reason).  N ranks split the fill N ways at best and cost
+    launch_cost_seconds(N) before they start; when that is more than they save, one GPU is faster."""
+    requested = max(1, int(requested))
+    if requested == 1:
+        return 1, "one GPU requested"
+    if os.environ.get("PHAMCLUST_FORCE_GPUS"):
+        return requested, "PHAMCLUST_FORCE_GPUS is set: no estimate"
+    one = estimate_fill_seconds(packed, metric)
+    saved = one * (1.0 - 1.0 / requested)
+    cost = launch_cost_seconds(requested)
+    if saved <= cost:
+        return 1, (f"estimated {metric} fill of {packed.n_genomes} genomes on one GPU: {one:.2f} s; {requested} ranks would save at most "
+                   f"{saved:.2f} s and cost ~{cost:.1f} s to start (interpreters, torch, process group): running on ONE GPU")
+    return requested, (f"estimated {metric} fill on one GPU: {one:.2f} s; {requested} ranks save up to {saved:.2f} s for ~{cost:.1f} s of start-up")

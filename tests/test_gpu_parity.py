@@ -424,6 +424,82 @@ def test_long_and_ragged_sequences(gpu_ctx, native_built):
     assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
 
 
+def _mutated(rng, seq, alphabet, sub=0.1, indel=0.01):
+    out = []
+    for ch in seq:
+        u = rng.random()
+        if u < indel:
+            continue                                          # deletion
+        out.append(alphabet[rng.integers(0, len(alphabet))] if u < indel + sub else ch)
+        if rng.random() < indel:
+            out.append(alphabet[rng.integers(0, len(alphabet))])   # insertion
+    return "".join(out)
+
+
+def test_strip_mined_long_column_genes(gpu_ctx, native_built):
+    """Column genes beyond 4,096 residues run strip-mined on the systolic kernel (k_nw_strip: passes of 64 x W columns, the
+    last column's (Ho, E) of every row step handed to the next pass through an HBM line) -- the reference's aligner has no length
+    cliff (metrics.py:160-175).  Homolog pairs of 4,097 ... 20,000 residues, both sides long, long columns against short rows and
+    the reverse, a tie-heavy 3-letter alphabet among them, under tie rules 0 and 3 (the cyclic one carries two differently tagged
+    copies of Ho across the pass boundary too): (n_ident, n_diag) equal the oracle's through the chooser and through each wide
+    variant forced; aai / peq fills over genomes holding such genes, and percent-positives (profile cell, passes of 1,536
+    columns, column genes up to 8,191 residues) likewise."""
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(404)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    ags = np.array(list("AGS"))
+    g, h = Genome("g0"), Genome("g1")
+    lens = [150, 1200, 3000, 4097, 5000, 6200, 9000, 20000]
+    for k, ln in enumerate(lens):
+        alpha = ags if ln in (4097, 6200) else aa
+        base = "".join(alpha[rng.integers(0, len(alpha), ln)])
+        g.add(f"p{k}", base)
+        h.add(f"p{k}", _mutated(rng, base, alpha))
+    g.add("p4", "".join(aa[rng.integers(0, 20, 5100)]))       # a paralog of the 5,000-residue gene: the anchor has a choice
+    pk = pack_genomes([g, h])
+    lens_all = np.diff(pk.seq_off)
+    G = pk.n_genes
+    a, b = np.meshgrid(np.arange(G, dtype=np.int32), np.arange(G, dtype=np.int32))
+    a, b = a.ravel(), b.ravel()
+    keep = (lens_all[b] > 4096) & ((lens_all[a] < 4000) | (np.abs(lens_all[a].astype(np.int64) - lens_all[b]) < 1500) | (rng.random(a.shape[0]) < 0.15))
+    a, b = a[keep], b[keep]
+    assert a.size >= 40 and (lens_all[a] > 9000).any()
+    gp, hp = Genome("q0"), Genome("q1")
+    for k, ln in enumerate([700, 1600, 3000, 5000, 8100]):
+        base = "".join(aa[rng.integers(0, 20, ln)])
+        gp.add(f"p{k}", base)
+        hp.add(f"p{k}", _mutated(rng, base, aa))
+    pk_ppos = pack_genomes([gp, hp])
+    a_pp, b_pp = np.meshgrid(np.arange(10, dtype=np.int32), np.arange(10, dtype=np.int32))
+    a_pp, b_pp = a_pp.ravel(), b_pp.ravel()
+    try:
+        for rule in (0, 3):
+            gpu_ctx.set_tie_rule(rule)
+            O.set_tie_rule(rule)
+            _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
+            gpu_ctx.upload(pk)
+            for variant in (0, 32, 48, 64):
+                ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
+                assert np.array_equal(ident, wi) and np.array_equal(diag, wd), f"rule {rule} variant {variant}"
+            if rule == 0:
+                sel = (lens_all[b] < 5500) & (lens_all[a] < 5500)          # the one-lane-per-alignment kernel agrees (it stays as the fallback;
+                ident, diag = gpu_ctx.align_pairs(a[sel], b[sel], variant=-1)   # 3 x 10^7 cells on ONE lane take seconds: only the shorter pairs)
+                assert sel.sum() >= 10 and np.array_equal(ident, wi[sel]) and np.array_equal(diag, wd[sel])
+            for metric in ("aai", "peq"):
+                assert np.array_equal(gpu_ctx.fill(metric), O.fill(pk, metric)), f"rule {rule} {metric}"
+            # percent-positives: the profile cell, passes of 64 x 24 columns, for column genes of 1,537 ... 8,191 residues
+            gpu_ctx.upload(pk_ppos)
+            assert np.array_equal(gpu_ctx.fill("aai_ppos"), O.fill(pk_ppos, "aai_ppos")), f"rule {rule} aai_ppos"
+            ident, diag = gpu_ctx.align_pairs(a_pp, b_pp)
+            _, wi, wd = O.nw_batch(pk_ppos.residues, pk_ppos.seq_off, a_pp, b_pp)
+            assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
+    finally:
+        O.set_tie_rule(0)
+        gpu_ctx.set_tie_rule(0)
+
+
 def test_shard_and_assemble_single_gpu(gpu_ctx, native_built):
     """Shard-local fills of every rank of a 3-way and a 4-way split, gathered by hand and
     assembled on the device, equal the unsharded condensed result."""
@@ -854,6 +930,8 @@ def test_bench_two_ranks_rehearsal(native_built):
     for key in ("plan_max_over_ranks", "align_max_over_ranks", "reduce_max_over_ranks", "exchange_rank0", "assemble_rank0", "exchange_bytes"):
         assert key in d["stage_ms"], key
     assert d["stage_ms"]["align_max_over_ranks"] > 0 and d["stage_ms"]["exchange_rank0"] > 0 and d["stage_ms"]["assemble_rank0"] > 0
+    # the fixed cost of being two ranks travels with the line: start-up seconds and the rate one matrix gets with them
+    assert d["init_s"] > 0.5 and d["upload_s"] > 0 and 0 < d["value_wall_incl_init"] < d["value"]
     lo, hi = d["shards"]["pairs_min_max"]
     assert 0 < lo <= hi and lo + hi == 301 * 300 // 2
 
@@ -1422,3 +1500,38 @@ print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_RAW_STAGE_MAX="0"), capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
+
+
+def test_real_collection_shape_full_matrix(gpu_ctx, native_built):
+    """The second workload (phamclust_amd.synth.synth_real: power-law clusters, ~6 N phams most of them with 1-3 holders, > 60 %
+    byte-identical proteins inside a cluster, paralog runs up to 8, 5-8 k-residue proteins, 2-column "M" genomes) at N = 1,000:
+    the WHOLE matrix of every metric against the oracle, whichever kernels the selector and the planner pick for it, plus every
+    set-metric family forced (metrics.py:26-253; the selector's thresholds were all tuned on synth(N, 5000))."""
+    from phamclust_amd.synth import synth_real
+    O = _oracle()
+    pk = synth_real(1000)
+    lens = np.diff(pk.seq_off)
+    assert (lens > 4096).any() and pk.n_phams > 5000 and (pk.tlen == pk.ngen).any()      # long genes, many phams, an "M" genome
+    gpu_ctx.upload(pk)
+    picked = {}
+    n = pk.n_genomes
+    rng = np.random.default_rng(8)
+    for metric in ALL_METRICS:
+        got, st = gpu_ctx.fill(metric, want_stats=True)
+        got = np.asarray(got).copy()
+        if metric == "aai":                                    # (the checker needs ~1 min of 16 cores per alignment metric at this size:
+            lo = rng.integers(0, n - 1, 20000); hi = rng.integers(0, n, 20000)       # peq gets the whole matrix, aai 20,000 random pairs)
+            lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
+            keep = lo < hi; lo, hi = lo[keep], hi[keep]
+            assert np.array_equal(got[lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)], O.pairs(pk, metric, lo, hi)), metric
+        else:
+            assert np.array_equal(got, O.fill(pk, metric)), metric
+        picked[metric] = gpu_ctx.last_set_kernel() if metric in SET_METRICS else (st["n_distinct_alignments"], st["n_alignments"])
+    assert picked["peq"][0] < 0.7 * picked["peq"][1]                                       # most alignments are repeats of identical proteins
+    try:
+        for kernel in ("popc", "sparse", "sparse64", "walker"):
+            os.environ["PC_SET_KERNEL"] = kernel
+            for metric in SET_METRICS:
+                assert np.array_equal(gpu_ctx.fill(metric), O.fill(pk, metric)), (kernel, metric)
+    finally:
+        os.environ.pop("PC_SET_KERNEL", None)

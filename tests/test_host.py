@@ -420,3 +420,35 @@ def test_chunk_plan_arithmetic(native_built):
     # uint64 overflow of the running sum is a cut, not a wrap
     big = np.array([2 ** 63, 2 ** 63, 5], dtype=np.uint64)
     assert hip.Context.chunk_plan(big, 2 ** 64 - 1).tolist() == [0, 1, 3]
+
+
+def test_gpus_request_is_clamped_to_the_work(native_built, tmp_path, monkeypatch):
+    """`--gpus N` starts N ranks only when they can win back what starting them costs (the reference clamps its workers to
+    the work as well, matrix.py:460-462).  The estimate is host arithmetic on the loaded genomes, before any GPU call; the
+    log line says why the run stayed on one GPU."""
+    from phamclust_amd import startup
+    from phamclust_amd.synth import synth_packed
+    small = synth_packed(120, 1500, seed=4)
+    cells = startup.alignment_cells(small)
+    from oracle import oracle as O
+    _, n_aln, n_cells = O.fill_rows(small, "peq", 0, small.n_genomes)
+    assert n_cells <= cells <= 1.2 * n_cells                       # an upper estimate, close (paralog-vs-paralog repeats only)
+    n, why = startup.choose_gpus(8, small, "peq")
+    assert n == 1 and "running on ONE GPU" in why and "8 ranks" in why
+    assert startup.choose_gpus(1, small, "peq")[0] == 1
+    assert startup.choose_gpus(4, small, "jc")[0] == 1             # set metrics: microseconds of kernel, never worth a launch
+    monkeypatch.setenv("PHAMCLUST_LAUNCH_COST_S", "0.000001")
+    n, why = startup.choose_gpus(8, small, "peq")
+    assert n == 8 and "save up to" in why
+    monkeypatch.delenv("PHAMCLUST_LAUNCH_COST_S")
+    monkeypatch.setenv("PHAMCLUST_FORCE_GPUS", "1")                # what the launcher sets for the ranks it starts
+    assert startup.choose_gpus(8, small, "peq")[0] == 8
+    # a fill that does outweigh the start-up: cells scaled up by pretending every gene is 40 x longer
+    monkeypatch.delenv("PHAMCLUST_FORCE_GPUS")
+    import copy
+    big = copy.copy(small)
+    big.seq_off = small.seq_off * 40
+    assert startup.estimate_fill_seconds(big, "peq") > 1600 * 0.9 * startup.estimate_fill_seconds(small, "peq") - 1.0
+    line = startup.Timeline()
+    line.mark("imports")
+    assert line.line().startswith("timing: {") and "imports" in line.as_dict()
