@@ -237,6 +237,16 @@ def main():
         agg_sum = agg.clone(); dist.all_reduce(agg_sum, op=dist.ReduceOp.SUM)
         agg_max = agg.clone(); dist.all_reduce(agg_max, op=dist.ReduceOp.MAX)
         agg_min = agg.clone(); dist.all_reduce(agg_min, op=dist.ReduceOp.MIN)
+        # the fixed cost of being N ranks (every rank takes part: max over ranks): process start -> group ready, and one upload
+        t = torch.tensor([init_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        init_s = float(t.item())
+        t0 = time.perf_counter()
+        ctx.upload(packed, residues=needs_residues)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        upload_s = float(t.item())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -349,15 +359,8 @@ def main():
         line["shards"] = shard_span
         # the fixed cost of being N ranks, and the rate a user of one matrix sees with it: process start -> group ready (max over
         # ranks), + one upload, + one fill with its exchange (the timed step)
-        t = torch.tensor([init_s], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        line["init_s"] = float(t.item())
-        t0 = time.perf_counter()
-        ctx.upload(packed, residues=needs_residues)
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        line["upload_s"] = float(t.item())
+        line["init_s"] = init_s
+        line["upload_s"] = upload_s
         line["value_wall_incl_init"] = n_pairs / (line["init_s"] + line["upload_s"] + elapsed / a.steps) if n_pairs else 0.0
         line["init_note"] = ("init_s: process start -> torch imported, process group initialised, first barrier passed (max over ranks); "
                              "value_wall_incl_init = pairs / (init_s + upload_s + one step): what ONE matrix costs a job that has to start its ranks first")

@@ -1007,20 +1007,48 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         else if (pc_launch_is_strip(v, l.max_lb)) sbytes = std::max(sbytes, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
     }
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
+    // Launch classes of one register tier, cell and workgroup size share ONE launch (k_nw_systolic_tier, pc_nw_fuse_key): the
+    // hardware queues run launches back to back, each waiting for the last workgroup of the one before it, and a fill's ~80
+    // launches cost it a task's duration each -- bundled they are ~15, each holding more tasks than the chip does at once.
+    // Groups keep the order of their first member (longest column genes first); inside a group the classes follow that order too.
+    struct Group { int key; std::vector<int> members; };
+    std::vector<Group> groups;
+    for (int i = 0; i < (int)launches.size(); ++i) {
+        const Launch& l = launches[i];
+        const int key = pc_nw_fuse_key(launch_variant(l), l.max_lb, ppos, pc_class_compare_only(l.base), l.mode);
+        size_t g = groups.size();
+        if (key >= 0) for (size_t k = 0; k < groups.size(); ++k) if (groups[k].key == key && groups[k].members.size() < PC_FUSE_MAX_SEGMENTS) { g = k; break; }
+        if (g == groups.size()) groups.push_back({key, {}});
+        groups[g].members.push_back(i);
+    }
     constexpr int kAux = pc_ctx::kAux;
-    const int n_aux = std::min((int)launches.size(), c->n_streams) - 1;      // auxiliary streams this fill uses
+    const int n_aux = std::min((int)groups.size(), c->n_streams) - 1;        // auxiliary streams this fill uses
     PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
     for (int k = 0; k < n_aux; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[kAux], 0));
     int slot = 0, first_error = PC_OK;
-    for (const Launch& l : launches) {
-        const int nt = (int)(l.end - l.begin);
-        const int variant = launch_variant(l);
-        // launches that use the one scratch slab stay in order on the caller's stream
-        const bool slab = uses_slab(l);
-        hipStream_t ls = (slab || slot == 0) ? st : c->aux[slot - 1];
-        int rc = pc_launch_nw(variant, c->dev, task_list + l.begin, nt, c->b_bucket_row.as<int32_t>(),
-                              nullptr /* result slot = position in the sorted list */, res, slab ? c->b_scratch.p : nullptr,
+    for (const Group& grp : groups) {
+        int rc = PC_OK;
+        if (grp.key >= 0) {
+            PcNwSegment segs[PC_FUSE_MAX_SEGMENTS];
+            int ns = 0;
+            for (int i : grp.members) {
+                const Launch& l = launches[i];
+                segs[ns++] = {l.begin, l.end - l.begin, launch_variant(l), l.max_lb, pc_class_compare_only(l.base), l.mode};
+            }
+            hipStream_t ls = slot == 0 ? st : c->aux[slot - 1];
+            rc = pc_launch_nw_group(segs, ns, c->dev, task_list, c->b_bucket_row.as<int32_t>(), nullptr /* result slot = position in the sorted list */,
+                                    res, ppos, c->tie_rule, ls);
+        } else {
+            const Launch& l = launches[grp.members[0]];
+            const int nt = (int)(l.end - l.begin);
+            const int variant = launch_variant(l);
+            // launches that use the one scratch slab stay in order on the caller's stream
+            const bool slab = uses_slab(l);
+            hipStream_t ls = (slab || slot == 0) ? st : c->aux[slot - 1];
+            rc = pc_launch_nw(variant, c->dev, task_list + l.begin, nt, c->b_bucket_row.as<int32_t>(),
+                              nullptr, res, slab ? c->b_scratch.p : nullptr,
                               slab ? c->b_scratch.cap : 0, l.max_lb, ppos, c->tie_rule, pc_class_compare_only(l.base), ls, l.mode, c->max_gene_len);
+        }
         if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
         slot = (slot + 1) % (n_aux + 1);

@@ -163,6 +163,12 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
                  const uint32_t* bucket_dest, uint2* res, void* scratch, size_t scratch_bytes, int max_lb, int ppos, int tie_rule, int compare_only, hipStream_t st,
                  int wave_mode = 0,    // wave_mode: PC_MODE_* -- workgroup shape of the launch's tasks
                  int max_row_len = 65535);   // longest row sequence (sizes a strip-mined launch's boundary lines; see pc_nw_strip_scratch_bytes)
+// several launch classes in ONE launch (k_nw_systolic_tier): classes whose pc_nw_fuse_key agrees (and is >= 0) may share it
+#define PC_FUSE_MAX_SEGMENTS 32
+struct PcNwSegment { uint32_t task_begin, ntasks; int variant, max_lb, compare_only, wave_mode; };
+int pc_nw_fuse_key(int variant, int max_lb, int ppos, int compare_only, int wave_mode);
+int pc_launch_nw_group(const PcNwSegment* segs, int nsegs, const PcDev& d, const PcTask* task_list, const int32_t* bucket_row,
+                       const uint32_t* bucket_dest, uint2* res, int ppos, int tie_rule, hipStream_t st);
 size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu);    // scratch a strip-mined launch (max_lb > 64 x W of its variant) wants
 int pc_nw_strip_passes(int lb, int variant);                   // passes of 64 x W columns a column gene of lb residues takes on that variant (1: not strip-mined)
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

@@ -107,10 +107,10 @@ __global__ __launch_bounds__(64) void k_nw_general(PcDev d, const PcTask* __rest
 }
 // Tie rules 2..7 of the systolic kernel are instantiated in pc_nw_rules.hip (three objects): not here
 #define PC_EXT1R(W, R) extern template int pc_systolic_launch<W, R, false> PC_SYSTOLIC_SIG;
-#define PC_EXT2R(W, R) PC_EXT1R(W, R) extern template int pc_systolic_launch<W, R, true> PC_SYSTOLIC_SIG;
 #define PC_EXT1(W) PC_EXT1R(W, 2) PC_EXT1R(W, 3) PC_EXT1R(W, 4) PC_EXT1R(W, 5) PC_EXT1R(W, 6) PC_EXT1R(W, 7)
-#define PC_EXT2(W) PC_EXT2R(W, 2) PC_EXT2R(W, 3) PC_EXT2R(W, 4) PC_EXT2R(W, 5) PC_EXT2R(W, 6) PC_EXT2R(W, 7)
-PC_FOR_W2(PC_EXT2)
+#define PC_EXT_TIER_R(T, R) extern template int pc_tier_launch<T, R, false> PC_TIER_SIG; extern template int pc_tier_launch<T, R, true> PC_TIER_SIG;
+#define PC_EXT_TIER(T) PC_EXT_TIER_R(T, 2) PC_EXT_TIER_R(T, 3) PC_EXT_TIER_R(T, 4) PC_EXT_TIER_R(T, 5) PC_EXT_TIER_R(T, 6) PC_EXT_TIER_R(T, 7)
+PC_FOR_TIER(PC_EXT_TIER)
 PC_FOR_W1(PC_EXT1)
 #define PC_EXT_STRIP_R(W, INC, R) extern template int pc_strip_launch<W, R, INC> PC_STRIP_SIG;
 #define PC_EXT_STRIP(W, INC) PC_EXT_STRIP_R(W, INC, 2) PC_EXT_STRIP_R(W, INC, 3) PC_EXT_STRIP_R(W, INC, 4) PC_EXT_STRIP_R(W, INC, 5) PC_EXT_STRIP_R(W, INC, 6) PC_EXT_STRIP_R(W, INC, 7)
@@ -309,39 +309,101 @@ int pc_nw_task_mode(int lb, int rows, int variant) {
 }
 int pc_nw_small_modes_enabled() { return pc_nw_task_mode(64, 1, 0) != PC_MODE_CLASS; }
 
-template <int W, int RULE>
-static int launch_systolic_rule(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                                const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, hipStream_t st, int wave_mode) {
+// Shape of a systolic launch of one class: which cell it runs, waves per workgroup, dynamic LDS
+struct PcLaunchShape { int W, nw; bool inc16; size_t lds; };
+static int launch_shape(int variant, int max_lb, int ppos, int compare_only, int wave_mode, PcLaunchShape& sh) {
+    const int W = g_variant_w[variant];
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
+    const int cell_mode = ppos ? 2 : ((compare_only != 0 || wave_mode == PC_MODE_ONE_WAVE) ? 1 : 0);
     // small tasks (pc_nw_task_mode): all their rows fit one or two waves, and a workgroup sized for them leaves its LDS to others
-    const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : waves_for(W, Gmax, cell_mode);
-    bool inc16 = false;
-    if constexpr (W <= PC_INC16_MAX_W) inc16 = mode_inc16(W, Gmax, cell_mode);
-    const int ppos = cell_mode == 2;
-    if (ppos && !inc16) { pc_set_error("k_nw_systolic<%d>: percent-positives needs the profile cell (W <= %d)", W, PC_INC16_MAX_W); return PC_ERR_ARG; }
-    const size_t lds = systolic_lds_bytes(W, Gmax, nw, inc16, cell_mode == 2);
-    hipError_t e;
-    if constexpr (W <= PC_INC16_MAX_W) {
-        if (inc16) e = (hipError_t)pc_systolic_launch<W, RULE, true>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, ppos);
-        else e = (hipError_t)pc_systolic_launch<W, RULE, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, 0);
-    } else e = (hipError_t)pc_systolic_launch<W, RULE, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, 0);
-    if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d,%d> launch: %s", W, RULE, hipGetErrorString(e)); return PC_ERR_HIP; }
+    sh.W = W;
+    sh.nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : waves_for(W, Gmax, cell_mode);
+    sh.inc16 = W <= PC_INC16_MAX_W && mode_inc16(W, Gmax, cell_mode);
+    if (ppos && !sh.inc16) { pc_set_error("k_nw_systolic<%d>: percent-positives needs the profile cell (W <= %d)", W, PC_INC16_MAX_W); return PC_ERR_ARG; }
+    sh.lds = systolic_lds_bytes(W, Gmax, sh.nw, sh.inc16, cell_mode == 2);
     return PC_OK;
 }
-template <int W>
-static int launch_systolic(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row,
-                           const uint32_t* bucket_dest, uint2* res, int max_lb, int cell_mode, int rule, hipStream_t st, int wave_mode) {
+// Launch classes that may share one k_nw_systolic_tier launch get the same key (>= 0): same register tier, same cell, same waves
+// per workgroup -- and, for the one- and two-wave modes, the same lanes-per-segment bucket: their workgroups are small, so the
+// LDS of the widest profile in the launch would cost the narrow ones their occupancy (a 4- or 8-wave workgroup spends at most
+// ~9 KB of LDS per wave on the largest profile of its tier, within what the tier's registers let a CU hold anyway).
+// -1: launched on its own (wide variants, strip-mined passes, the general kernel).
+int pc_nw_fuse_key(int variant, int max_lb, int ppos, int compare_only, int wave_mode) {
+    static const bool off = getenv("PC_FUSE") && !atoi(getenv("PC_FUSE"));
+    if (variant < 0 || variant >= g_num_variants || max_lb > 64 * g_variant_w[variant]) return -1;
+    const int tier = pc_tier_of(g_variant_w[variant]);
+    if (tier < 0) return -1;
+    PcLaunchShape sh;
+    if (launch_shape(variant, max_lb, ppos, compare_only, wave_mode, sh) != PC_OK) return -1;
+    const int W = sh.W, G = std::min(64, (max_lb + W - 1) / W);
+    const int gb = wave_mode == PC_MODE_CLASS ? 0 : (pc_nw_g_bucket(G) == 8 ? 1 : pc_nw_g_bucket(G) == 16 ? 2 : pc_nw_g_bucket(G) == 32 ? 3 : 4);
+    const int key = (((tier * 2 + (sh.inc16 ? 1 : 0)) * 16 + sh.nw) * 8 + gb);
+    return off ? key * 64 + variant * 0 + 1000000 + (variant * 4096 + max_lb % 4096) : key;   // PC_FUSE=0: every class its own launch (A/B)
+}
+
+template <int TIER, bool INC16>
+static int launch_tier(int nblocks, int nw, size_t lds, const PcFuseArgs& f, const PcDev& d, const PcTask* tasks, const int32_t* bucket_row,
+                       const uint32_t* bucket_dest, uint2* res, int ppos, int rule, hipStream_t st) {
+    hipError_t e = hipSuccess;
     switch (rule) {
-    case 0: return launch_systolic_rule<W, 0>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 1: return launch_systolic_rule<W, 1>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 2: return launch_systolic_rule<W, 2>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 3: return launch_systolic_rule<W, 3>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 4: return launch_systolic_rule<W, 4>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 5: return launch_systolic_rule<W, 5>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 6: return launch_systolic_rule<W, 6>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
-    case 7: return launch_systolic_rule<W, 7>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, cell_mode, st, wave_mode);
+#define PC_TIER_CASE(R) case R: e = (hipError_t)pc_tier_launch<TIER, R, INC16>((unsigned)nblocks, nw, lds, st, d, tasks, f, bucket_row, bucket_dest, res, ppos); break;
+    PC_TIER_CASE(0) PC_TIER_CASE(1) PC_TIER_CASE(2) PC_TIER_CASE(3) PC_TIER_CASE(4) PC_TIER_CASE(5) PC_TIER_CASE(6) PC_TIER_CASE(7)
+#undef PC_TIER_CASE
     default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
     }
+    if (e != hipSuccess) { pc_set_error("k_nw_systolic_tier<%d,%d> launch: %s", TIER, rule, hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// One launch over several launch classes of one fuse key (pc_nw_fuse_key): `segs` = (first task, tasks, variant, longest column
+// gene, compare-only, wave mode) each, at most PC_FUSE_MAX_SEG of them, tasks taken from task_list.
+int pc_launch_nw_group(const PcNwSegment* segs, int nsegs, const PcDev& d, const PcTask* task_list, const int32_t* bucket_row,
+                       const uint32_t* bucket_dest, uint2* res, int ppos, int rule, hipStream_t st) {
+    if (nsegs <= 0) return PC_OK;
+    if (nsegs > PC_FUSE_MAX_SEG) { pc_set_error("pc_launch_nw_group: %d segments (limit %d)", nsegs, PC_FUSE_MAX_SEG); return PC_ERR_ARG; }
+    if (rule < 0 || rule >= PC_NUM_TIE_RULES) { pc_set_error("pc_launch_nw_group: tie rule %d out of range", rule); return PC_ERR_ARG; }
+    PcFuseArgs f; memset(&f, 0, sizeof(f));
+    int tier = -1, nw = 0; bool inc16 = false; size_t lds = 0; uint32_t blocks = 0;
+    for (int i = 0; i < nsegs; ++i) {
+        const PcNwSegment& sg = segs[i];
+        if (sg.variant < 0 || sg.variant >= g_num_variants || sg.max_lb > 64 * g_variant_w[sg.variant] || pc_tier_of(g_variant_w[sg.variant]) < 0) {
+            pc_set_error("pc_launch_nw_group: variant %d with %d columns has no tier kernel", sg.variant, sg.max_lb); return PC_ERR_ARG;
+        }
+        PcLaunchShape sh;
+        int rc = launch_shape(sg.variant, sg.max_lb, ppos, sg.compare_only, sg.wave_mode, sh);
+        if (rc != PC_OK) return rc;
+        const int t = pc_tier_of(sh.W);
+        if (i == 0) { tier = t; nw = sh.nw; inc16 = sh.inc16; }
+        else if (t != tier || sh.nw != nw || sh.inc16 != inc16) { pc_set_error("pc_launch_nw_group: segments of different tier / cell / workgroup size"); return PC_ERR_ARG; }
+        lds = std::max(lds, sh.lds);
+        blocks += sg.ntasks;
+        f.block_end[i] = blocks; f.task_begin[i] = sg.task_begin; f.w[i] = sh.W;
+    }
+    f.nseg = nsegs;
+    if (blocks == 0) return PC_OK;
+#define PC_TIER_GO(T) case T: return inc16 ? launch_tier<T, true>((int)blocks, nw, lds, f, d, task_list, bucket_row, bucket_dest, res, ppos, rule, st) \
+                                           : launch_tier<T, false>((int)blocks, nw, lds, f, d, task_list, bucket_row, bucket_dest, res, ppos, rule, st);
+    switch (tier) { PC_TIER_GO(0) PC_TIER_GO(1) PC_TIER_GO(2) PC_TIER_GO(3) default: break; }
+#undef PC_TIER_GO
+    pc_set_error("pc_launch_nw_group: no tier %d", tier); return PC_ERR_ARG;
+}
+
+// the wide variants (W = 32, 48, 64): a kernel each
+template <int W>
+static int launch_wide(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res,
+                       int max_lb, int wave_mode, int rule, hipStream_t st) {
+    int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
+    const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : waves_for(W, Gmax, 1);
+    const size_t lds = systolic_lds_bytes(W, Gmax, nw, false, false);
+    hipError_t e = hipSuccess;
+    switch (rule) {
+#define PC_WIDE_CASE(R) case R: e = (hipError_t)pc_systolic_launch<W, R, false>((unsigned)ntasks, nw, lds, st, d, tasks, bucket_row, bucket_dest, res, 0); break;
+    PC_WIDE_CASE(0) PC_WIDE_CASE(1) PC_WIDE_CASE(2) PC_WIDE_CASE(3) PC_WIDE_CASE(4) PC_WIDE_CASE(5) PC_WIDE_CASE(6) PC_WIDE_CASE(7)
+#undef PC_WIDE_CASE
+    default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
+    }
+    if (e != hipSuccess) { pc_set_error("k_nw_systolic<%d,%d> launch: %s", W, rule, hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
 }
 
 // Scratch of a strip-mined launch: one boundary line of (longest row + 2) 16-byte entries per wave of every resident workgroup
@@ -399,12 +461,15 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
             if (!ppos && W == 64) return launch_strip<64, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);
             pc_set_error("pc_launch_nw: variant %d (w = %d) cannot take %d columns", variant, W, max_lb); return PC_ERR_ARG;
         }
+        if (ppos && g_variant_w[variant] > PC_INC16_MAX_W) { pc_set_error("pc_launch_nw: percent-positives cannot run on variant %d", variant); return PC_ERR_ARG; }
         switch (g_variant_w[variant]) {
-#define PC_CASE(WW) case WW: return launch_systolic<WW>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, ppos ? 2 : ((compare_only != 0 || wave_mode == PC_MODE_ONE_WAVE) ? 1 : 0), rule, st, wave_mode);
-        PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8) PC_CASE(9) PC_CASE(10) PC_CASE(11)
-        PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16) PC_CASE(17) PC_CASE(18) PC_CASE(19) PC_CASE(20) PC_CASE(22) PC_CASE(24) PC_CASE(32) PC_CASE(48) PC_CASE(64)
-#undef PC_CASE
-        default: pc_set_error("pc_launch_nw: no kernel for variant %d", variant); return PC_ERR_ARG;
+        case 32: return launch_wide<32>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, wave_mode, rule, st);
+        case 48: return launch_wide<48>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, wave_mode, rule, st);
+        case 64: return launch_wide<64>(d, tasks, ntasks, bucket_row, bucket_dest, res, max_lb, wave_mode, rule, st);
+        default: {                                                               // a tier kernel with this one class as its only segment
+            PcNwSegment sg; sg.task_begin = 0; sg.ntasks = (uint32_t)ntasks; sg.variant = variant; sg.max_lb = max_lb; sg.compare_only = compare_only; sg.wave_mode = wave_mode;
+            return pc_launch_nw_group(&sg, 1, d, tasks, bucket_row, bucket_dest, res, ppos, rule, st);
+        }
         }
     }
     // general kernel: one scratch slab of 64 * max_lb cells per resident workgroup

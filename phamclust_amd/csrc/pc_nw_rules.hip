@@ -6,8 +6,9 @@
 #define PC_RULE_B 3
 #endif
 #define PC_INST1(W) template int pc_systolic_launch<W, PC_RULE_A, false> PC_SYSTOLIC_SIG; template int pc_systolic_launch<W, PC_RULE_B, false> PC_SYSTOLIC_SIG;
-#define PC_INST2(W) PC_INST1(W) template int pc_systolic_launch<W, PC_RULE_A, true> PC_SYSTOLIC_SIG; template int pc_systolic_launch<W, PC_RULE_B, true> PC_SYSTOLIC_SIG;
-PC_FOR_W2(PC_INST2)
+#define PC_INST_TIER(T) template int pc_tier_launch<T, PC_RULE_A, false> PC_TIER_SIG; template int pc_tier_launch<T, PC_RULE_B, false> PC_TIER_SIG; \
+                        template int pc_tier_launch<T, PC_RULE_A, true> PC_TIER_SIG; template int pc_tier_launch<T, PC_RULE_B, true> PC_TIER_SIG;
+PC_FOR_TIER(PC_INST_TIER)
 PC_FOR_W1(PC_INST1)
 // the strip-mined kernel (column genes beyond 64 x W columns): the three wide variants, and W = 24 with the profile cell (percent-positives)
 #define PC_INST_STRIP(W, INC) template int pc_strip_launch<W, PC_RULE_A, INC> PC_STRIP_SIG; template int pc_strip_launch<W, PC_RULE_B, INC> PC_STRIP_SIG;

@@ -256,13 +256,12 @@ typedef uint32_t pc_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const pc_u32x2 pc_lds_u32x2;
 typedef __attribute__((address_space(3))) const pc_u32x4 pc_lds_u32x4;
 
-// (second launch bound = waves per SIMD the compiler must leave room for: W = 48 needs 257 registers left to itself, one more
-// than the 256 that let two waves share a SIMD)
+// The kernel's body for one workgroup task (a device function: the wide variants get a kernel of their own, the others are
+// bundled by register tier into k_nw_systolic_tier below, which picks the body by the task's launch segment).
 template <int W, int RULE, bool INC16>
-__global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
-                                                               const int32_t* __restrict__ bucket_row,
-                                                               const uint32_t* __restrict__ bucket_dest,
-                                                               uint2* __restrict__ res, int ppos) {
+__device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restrict__ tasks, const uint32_t task_index,
+                                           const int32_t* __restrict__ bucket_row, const uint32_t* __restrict__ bucket_dest,
+                                           uint2* __restrict__ res, const int ppos) {
     constexpr int ND = (W + 3) / 4;                 // score dwords per lane per residue row
     static_assert(!INC16 || W <= PC_INC16_MAX_W, "INC16 variants");
     constexpr int NDM = INC16 ? (W + 1) / 2 : 0;    // statistics increments from the profile (PcRow): their dwords per lane per residue row
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_
     // profile bytes: 4 * (S + 12) (the bias note above, scaled to the score field of `hi`) + what turns the stored Ho's tag into DIAG's
     for (int i = threadIdx.x; i < 576; i += 64 * NWV) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
 
-    const PcTask tk = tasks[blockIdx.x];
+    const PcTask tk = tasks[task_index];
     const int lb = d.gene_len[tk.gene];
     const uint8_t* __restrict__ bp = d.codes + d.gene_off[tk.gene];
     const int G = (lb + W - 1) / W;                 // lanes per segment (<= 64 by variant choice)
@@ -842,16 +841,75 @@ int pc_strip_launch(unsigned nblocks, size_t lds, hipStream_t st, const PcDev& d
 }
 #define PC_STRIP_SIG (unsigned, size_t, hipStream_t, const PcDev&, const PcTask*, int, const int32_t*, const uint32_t*, uint2*, int, uint4*, unsigned)
 
-// One launch of k_nw_systolic<W, RULE, INC16>; returns the hipError_t of the launch.  The only thing a translation unit
-// needs to instantiate (explicitly, in pc_nw_rules.hip; implicitly for rules 0 and 1 in pc_nw.hip).
-// (hipExtLaunchKernel's hipExtAnyOrderLaunch -- launches of one queue without the AQL barrier bit, so that a launch need not wait
-// for the last workgroup of the one before it -- is ignored on gfx950: tests/hw/anyorder_probe.hip, profiles/r04/experiments)
+// ---- kernels over the body -------------------------------------------------------------------------------------
+// (second launch bound = waves per SIMD the compiler must leave room for: W = 48 needs 257 registers left to itself, one more
+// than the 256 that let two waves share a SIMD)
+template <int W, int RULE, bool INC16>
+__global__ __launch_bounds__(64 * pc_max_waves(W), (W == 48 ? 2 : 1)) void k_nw_systolic(PcDev d, const PcTask* __restrict__ tasks,
+                                                               const int32_t* __restrict__ bucket_row,
+                                                               const uint32_t* __restrict__ bucket_dest,
+                                                               uint2* __restrict__ res, int ppos) {
+    pc_nw_body<W, RULE, INC16>(d, tasks, blockIdx.x, bucket_row, bucket_dest, res, ppos);
+}
+
+// ONE launch for the launch classes of a register tier (r04).  Launches of a stream run back to back -- a launch waits for the
+// LAST workgroup of the one before it (the AQL barrier bit; hipExtLaunchKernel's hipExtAnyOrderLaunch, which would drop it, is
+// ignored on gfx950: tests/hw/anyorder_probe.hip) -- and HIP maps the streams onto four hardware queues, so a fill of ~80
+// launches, ~20 in a row per queue, spends a task's duration per launch with its queue feeding nothing: the 12 ms that a fill
+// costs whatever its size (T(w) = 11.8 + 572 / w ms for a 1/w share of the N = 5,000 fill).  The variants of a tier need about
+// the same registers -- the same waves per SIMD -- so their bodies share one kernel at no cost in occupancy; a launch then
+// holds the tasks of ~20 classes (its SEGMENTS: a block range each, with the variant that runs it), far more than the chip
+// holds at once, and only the last launches of a fill have a tail.  LDS and workgroup size are the launch's: the segments of a
+// launch agree on waves per workgroup, and the dynamic LDS is the largest any of them needs (pc_nw.hip groups them so that
+// this stays within what the tier's register budget lets a CU hold anyway).
+#define PC_FUSE_MAX_SEG PC_FUSE_MAX_SEGMENTS
+struct PcFuseArgs {
+    int32_t nseg;
+    uint32_t block_end[PC_FUSE_MAX_SEG];              // segment i holds blocks [block_end[i-1], block_end[i])
+    uint32_t task_begin[PC_FUSE_MAX_SEG];             // ... which are tasks task_begin[i] + (block - block_end[i-1])
+    int32_t w[PC_FUSE_MAX_SEG];                       // ... run by the body of this many columns per lane
+};
+// tiers by registers (waves per SIMD): 2..8 (<= 72: seven or more), 9..12 (<= 92: five), 13..19 (<= 128: four), 20..24 (<= 152: three)
+#define PC_NUM_TIERS 4
+__host__ __device__ constexpr int pc_tier_of(int W) { return W <= 8 ? 0 : W <= 12 ? 1 : W <= 19 ? 2 : W <= 24 ? 3 : -1; }
+
+// (second launch bound: the waves per SIMD the tier's widest body reaches on its own -- bundled, tier 2's profile-cell kernel
+// came out at 130 registers, two past the 128 of four waves per SIMD)
+__host__ __device__ constexpr int pc_tier_waves_per_simd(int tier) { return tier == 0 ? 7 : tier == 1 ? 5 : tier == 2 ? 4 : 3; }
+template <int TIER, int RULE, bool INC16>
+__global__ __launch_bounds__(64 * 8, pc_tier_waves_per_simd(TIER)) void k_nw_systolic_tier(PcDev d, const PcTask* __restrict__ tasks, PcFuseArgs f,
+                                                              const int32_t* __restrict__ bucket_row, const uint32_t* __restrict__ bucket_dest,
+                                                              uint2* __restrict__ res, int ppos) {
+    int seg = 0;
+    uint32_t first = 0;
+    while (seg + 1 < f.nseg && blockIdx.x >= f.block_end[seg]) { first = f.block_end[seg]; ++seg; }     // (scalar: blockIdx is wave-uniform)
+    const uint32_t task = f.task_begin[seg] + (blockIdx.x - first);
+    const int w = f.w[seg];
+#define PC_BODY(WW) case WW: pc_nw_body<WW, RULE, INC16>(d, tasks, task, bucket_row, bucket_dest, res, ppos); break;
+    if constexpr (TIER == 0) { switch (w) { PC_BODY(2) PC_BODY(3) PC_BODY(4) PC_BODY(5) PC_BODY(6) PC_BODY(7) PC_BODY(8) default: break; } }
+    else if constexpr (TIER == 1) { switch (w) { PC_BODY(9) PC_BODY(10) PC_BODY(11) PC_BODY(12) default: break; } }
+    else if constexpr (TIER == 2) { switch (w) { PC_BODY(13) PC_BODY(14) PC_BODY(15) PC_BODY(16) PC_BODY(17) PC_BODY(18) PC_BODY(19) default: break; } }
+    else { switch (w) { PC_BODY(20) PC_BODY(22) PC_BODY(24) default: break; } }
+#undef PC_BODY
+}
+
+// One launch of k_nw_systolic<W, RULE, INC16> (the wide variants) / k_nw_systolic_tier<TIER, RULE, INC16>; both return the
+// hipError_t of the launch.  The only things a translation unit needs to instantiate (explicitly, in pc_nw_rules.hip;
+// implicitly for rules 0 and 1 in pc_nw.hip).
 template <int W, int RULE, bool INC16>
 int pc_systolic_launch(unsigned ntasks, int nw, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks,
                        const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos) {
     hipLaunchKernelGGL((k_nw_systolic<W, RULE, INC16>), dim3(ntasks), dim3(64 * nw), lds, st, d, tasks, bucket_row, bucket_dest, res, ppos);
     return (int)hipGetLastError();
 }
+template <int TIER, int RULE, bool INC16>
+int pc_tier_launch(unsigned nblocks, int nw, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks, const PcFuseArgs& f,
+                   const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos) {
+    hipLaunchKernelGGL((k_nw_systolic_tier<TIER, RULE, INC16>), dim3(nblocks), dim3(64 * nw), lds, st, d, tasks, f, bucket_row, bucket_dest, res, ppos);
+    return (int)hipGetLastError();
+}
+#define PC_TIER_SIG (unsigned, int, size_t, hipStream_t, const PcDev&, const PcTask*, const PcFuseArgs&, const int32_t*, const uint32_t*, uint2*, int)
+#define PC_FOR_TIER(M) M(0) M(1) M(2) M(3)
 
 
 // X-macro over the compiled widths: PC_FOR_W2(M) for those that exist with both cells, PC_FOR_W1(M) for the wide ones

@@ -271,6 +271,7 @@ def phamclust(infile, outdir, is_genome_dir, metric, nr_distance, nr_linkage, cl
         log.info(f"{key:<11}{value}")
     run = _Run(outdir, metric, colors, midpoint)
     run.rank, run.world = distributed.ensure_process_group()      # (0, 1) unless started by torch.distributed.run
+    _mark("torch_import_and_process_group")
     run.read(infile, is_genome_dir)
     matrix = run.distances(cpus)
     if matrix is None:                        # ranks other than 0 are done once their shard is gathered

@@ -15,9 +15,11 @@ import time
 import numpy as np
 
 # Measured on the one-GPU box with the launcher and the gloo rehearsal transport (tools/launch_cost.py ->
-# profiles/r04/launch_cost.txt): seconds from `phamclust --gpus N` being started to the ranks' first GPU call, minus the same
-# for `--gpus 1` -- the launcher process, N interpreters importing torch, the process group.  PHAMCLUST_LAUNCH_COST_S overrides.
-LAUNCH_COST_S = 6.0
+# profiles/r04/launch_cost.txt, synth(5000,5000) -m peq): command start -> matrix on the host 2.73 s on one rank, 5.23 s as 2 ranks,
+# 5.34 s as 4 -- the parent's own start, its load for this estimate and the launcher 1.7 s, the ranks' torch import and process
+# group ~1.05 s -- i.e. ~2.5 s of fixed cost, while the fill stage itself was no faster (the ranks shared one GPU there).  RCCL's
+# communicator set-up, which gloo does not pay, is allowed one more second.  PHAMCLUST_LAUNCH_COST_S overrides.
+LAUNCH_COST_S = 3.5
 # one GPU, sustained (bench.py / profiles/): DP cells per second of the alignment kernels, genome pairs per second of the
 # set-metric kernels, bytes per second of the D2H copy into pinned memory
 CELLS_PER_S = 3.3e12

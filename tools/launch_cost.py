@@ -44,7 +44,7 @@ for ranks in [int(x) for x in a.ranks.split(",")]:
     lines.append(f"--gpus {ranks}: " + json.dumps(best))
     print(lines[-1], flush=True)
 if 1 in rows:
-    keys = ("interpreter_start", "imports", "load_genomes_for_estimate", "load_genomes", "pack", "process_group_and_context", "upload", "fill_exchange_d2h")
+    keys = ("interpreter_start", "imports", "load_genomes_for_estimate", "torch_import_and_process_group", "load_genomes", "pack", "process_group_and_context", "upload", "fill_exchange_d2h")
     base = sum(rows[1].get(k, 0.0) for k in keys)
     for ranks, t in rows.items():
         if ranks > 1:
