@@ -323,7 +323,7 @@ static int pc_class_variant(int cls) {
 }
 static int pc_class_compare_only(int cls) { const int nvar = pc_nw_num_variants(); return cls >= nvar * 4 && cls < nvar * 8; }
 // a launch whose longest column gene exceeds its variant's 64 x W columns runs strip-mined and needs the scratch slab
-static bool pc_launch_is_strip(int variant, int max_lb) { return variant >= 0 && max_lb > 64 * pc_nw_variant_w(variant); }
+static bool pc_launch_is_strip(int variant, int max_lb, int mode, int ppos) { return pc_nw_launch_is_strip(variant, max_lb, mode, ppos) != 0; }
 
 static int apply_shard(pc_ctx* c, int rank, int world) {
     c->plan.valid = false;                             // a plan belongs to the shard it was made for
@@ -836,7 +836,7 @@ static int upload_residues(pc_ctx* c, const pc_packed* g) {
     }
     c->task_plan.task_rows = c->b_task_rows.as<int32_t>(); c->task_plan.q_class = c->b_q_class.as<uint8_t>();
     c->task_plan.q_nseg = c->b_q_nseg.as<uint8_t>(); c->task_plan.rem_class = c->b_rem_class.as<uint8_t>();
-    c->task_plan.nvar = pc_nw_num_variants(); c->task_plan.small_modes = pc_nw_small_modes_enabled();
+    c->task_plan.nvar = pc_nw_num_variants(); c->task_plan.small_modes = pc_nw_small_modes_enabled(); c->task_plan.n_strip = PC_STRIP_CLASSES; c->task_plan.pad_ = 0;
     for (int v = 0; v < 32; ++v) c->task_plan.variant_w[v] = v < pc_nw_num_variants() ? pc_nw_variant_w(v) : 0;
     {   // launch classes: every base class in its three workgroup shapes, each with the base class's longest column gene
         std::vector<int32_t> per_base; per_base.swap(c->cls_max_lb);
@@ -977,7 +977,10 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         const uint32_t* tb = task_begin + (size_t)b * PC_WAVE_MODES;
         if (tb[PC_WAVE_MODES] == tb[0]) continue;
         const uint32_t n0 = tb[1] - tb[0], n1 = tb[2] - tb[1], n2 = tb[3] - tb[2];
-        const uint32_t least = (uint32_t)small_launch_min();
+        // (the wide variants' tasks are hundreds of times a small gene's, and their one- / two-row tasks run on another kernel
+        // altogether -- narrow strip-mined passes: always worth a launch)
+        const int bv = pc_class_variant(b);
+        const uint32_t least = (bv >= 0 && pc_nw_variant_w(bv) >= 32) ? 1u : (uint32_t)small_launch_min();
         const bool own2 = n2 >= least, own1 = n1 + (own2 ? 0u : n2) >= least;      // one-wave tasks alone? two-wave (+ folded one-wave) alone?
         uint32_t at = tb[0];
         const int max_lb = cls_max_lb[b * PC_WAVE_MODES];
@@ -1000,11 +1003,11 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     size_t sbytes = 0;
     // percent-positives: systolic where the profile cell can run (it reads "positive" from a table), general kernel elsewhere
     auto launch_variant = [&](const Launch& l) { const int v = pc_class_variant(l.base); return (ppos && !pc_nw_ppos_systolic(v, l.max_lb)) ? pc_nw_ppos_variant(l.max_lb) : v; };
-    auto uses_slab = [&](const Launch& l) { const int v = launch_variant(l); return v < 0 || pc_launch_is_strip(v, l.max_lb); };
+    auto uses_slab = [&](const Launch& l) { const int v = launch_variant(l); return v < 0 || pc_launch_is_strip(v, l.max_lb, l.mode, ppos); };
     for (const Launch& l : launches) {
         const int v = launch_variant(l);
         if (v < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(l.max_lb));
-        else if (pc_launch_is_strip(v, l.max_lb)) sbytes = std::max(sbytes, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
+        else if (pc_launch_is_strip(v, l.max_lb, l.mode, ppos)) sbytes = std::max(sbytes, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
     }
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     // Launch classes of one register tier, cell and workgroup size share ONE launch (k_nw_systolic_tier, pc_nw_fuse_key): the
@@ -1709,7 +1712,7 @@ extern "C" int pc_align_pairs(pc_ctx* c, const int32_t* a_gene, const int32_t* b
         if (nt <= 0) continue;
         void* scratch = nullptr; size_t sbytes = 0;
         const int base = lc / PC_WAVE_MODES, v = pc_class_variant(base);
-        if (v < 0 || pc_launch_is_strip(v, cls_maxlb[lc])) {
+        if (v < 0 || pc_launch_is_strip(v, cls_maxlb[lc], lc % PC_WAVE_MODES, 0)) {
             sbytes = v < 0 ? pc_nw_fallback_scratch_bytes(cls_maxlb[lc]) : pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu);
             if ((rc = c->b_scratch.ensure(sbytes))) { cleanup(); return abi_rc(rc); }
             scratch = c->b_scratch.p; sbytes = c->b_scratch.cap;

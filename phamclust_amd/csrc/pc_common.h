@@ -72,6 +72,7 @@ struct PcTaskPlan {
     const uint8_t* q_nseg;            // [U] segments per wave of the main variant
     const uint8_t* rem_class;         // [U][16] launch class for a remainder of r rows (r = n mod nseg), 255: keep them in the main task
     int32_t nvar, small_modes;        // systolic variants; 1: tasks of at most nseg / 2 nseg rows get the one- / two-wave modes
+    int32_t n_strip, pad_;            // strip-mined base classes (they follow the 2 x nvar x 4 systolic ones)
     int32_t variant_w[32];            // columns per lane of variant v
 };
 
@@ -170,5 +171,6 @@ int pc_nw_fuse_key(int variant, int max_lb, int ppos, int compare_only, int wave
 int pc_launch_nw_group(const PcNwSegment* segs, int nsegs, const PcDev& d, const PcTask* task_list, const int32_t* bucket_row,
                        const uint32_t* bucket_dest, uint2* res, int ppos, int tie_rule, hipStream_t st);
 size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu);    // scratch a strip-mined launch (max_lb > 64 x W of its variant) wants
+int pc_nw_launch_is_strip(int variant, int max_lb, int wave_mode, int ppos);   // the launch runs on k_nw_strip and needs the scratch slab
 int pc_nw_strip_passes(int lb, int variant);                   // passes of 64 x W columns a column gene of lb residues takes on that variant (1: not strip-mined)
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

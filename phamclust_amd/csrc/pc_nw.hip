@@ -114,7 +114,7 @@ PC_FOR_TIER(PC_EXT_TIER)
 PC_FOR_W1(PC_EXT1)
 #define PC_EXT_STRIP_R(W, INC, R) extern template int pc_strip_launch<W, R, INC> PC_STRIP_SIG;
 #define PC_EXT_STRIP(W, INC) PC_EXT_STRIP_R(W, INC, 2) PC_EXT_STRIP_R(W, INC, 3) PC_EXT_STRIP_R(W, INC, 4) PC_EXT_STRIP_R(W, INC, 5) PC_EXT_STRIP_R(W, INC, 6) PC_EXT_STRIP_R(W, INC, 7)
-PC_EXT_STRIP(32, false) PC_EXT_STRIP(48, false) PC_EXT_STRIP(64, false) PC_EXT_STRIP(24, true)
+PC_EXT_STRIP(32, false) PC_EXT_STRIP(48, false) PC_EXT_STRIP(64, false) PC_EXT_STRIP(24, true) PC_EXT_STRIP(8, false) PC_EXT_STRIP(12, false)
 
 // columns-per-lane of the compiled systolic variants
 static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 32, 48, 64};
@@ -136,6 +136,14 @@ int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants ||
 // a pass costing a row step of that variant per row whatever its width -- the fewest step-instructions win (W = 32 / 48 / 64:
 // 2,048 / 3,072 / 4,096 columns per pass; penalties as below).  PC_STRIP=0 sends them to the general kernel as r01-r03 did.
 static bool strip_enabled() { static const bool off = getenv("PC_STRIP") && !atoi(getenv("PC_STRIP")); return !off; }
+// Does a launch of this class run on k_nw_strip (and need the scratch slab)?  Column genes beyond the variant's 64 x W columns
+// always; and the one- / two-row tasks of the wide variants' ordinary classes, which narrow passes serve better (see PC_STRIP_W_*).
+int pc_nw_launch_is_strip(int variant, int max_lb, int wave_mode, int ppos) {
+    if (variant < 0 || variant >= g_num_variants) return 0;
+    const int W = g_variant_w[variant];
+    if (max_lb > 64 * W) return 1;
+    return (!ppos && W >= 32 && wave_mode != PC_MODE_CLASS && strip_enabled()) ? 1 : 0;
+}
 int pc_nw_strip_passes(int lb, int variant) {
     if (variant < 0 || variant >= g_num_variants || lb <= 0) return 0;
     const int cols = 64 * g_variant_w[variant];
@@ -303,8 +311,7 @@ int pc_nw_task_mode(int lb, int rows, int variant) {
     static const int off = getenv("PC_SMALL_MODES") ? !atoi(getenv("PC_SMALL_MODES")) : 0;       // PC_SMALL_MODES=0: every task in its class's own workgroup shape
     if (off || variant < 0 || variant >= g_num_variants || lb <= 0) return PC_MODE_CLASS;
     const int W = g_variant_w[variant], G = (lb + W - 1) / W;
-    if (G > 64) return PC_MODE_CLASS;                                         // strip-mined tasks have one shape
-    int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;
+    int nseg = G > 64 ? 1 : 64 / G; if (nseg > PC_MAX_SEG) nseg = PC_MAX_SEG;     // (G > 64: strip-mined, one row per wave)
     return rows <= nseg ? PC_MODE_ONE_WAVE : rows <= 2 * nseg ? PC_MODE_TWO_WAVES : PC_MODE_CLASS;
 }
 int pc_nw_small_modes_enabled() { return pc_nw_task_mode(64, 1, 0) != PC_MODE_CLASS; }
@@ -407,27 +414,27 @@ static int launch_wide(const PcDev& d, const PcTask* tasks, int ntasks, const in
 }
 
 // Scratch of a strip-mined launch: one boundary line of (longest row + 2) 16-byte entries per wave of every resident workgroup
-static size_t strip_bytes_per_block(int max_row_len) { return (size_t)PC_STRIP_WAVES * ((size_t)max_row_len + 2) * sizeof(uint4); }
+static size_t strip_bytes_per_block(int max_row_len, int nw = PC_STRIP_WAVES) { return (size_t)nw * ((size_t)max_row_len + 2) * sizeof(uint4); }
 size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu) {
-    const size_t per = strip_bytes_per_block(max_row_len);
-    size_t blocks = (size_t)2 * (n_cu > 0 ? n_cu : 256);
+    const size_t per = strip_bytes_per_block(max_row_len);                    // (sized for 4-wave workgroups, two per CU; one-wave launches
+    size_t blocks = (size_t)3 * (n_cu > 0 ? n_cu : 256);                      //  then get 12 workgroups per CU out of the same slab)
     const size_t budget = (size_t)1 << 30;
     if (blocks * per > budget) blocks = std::max<size_t>(budget / per, 8);
     return blocks * per;
 }
 template <int W, bool INC16>
 static int launch_strip(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res,
-                        void* scratch, size_t scratch_bytes, int max_row_len, int ppos, int rule, hipStream_t st) {
-    const size_t per = strip_bytes_per_block(max_row_len);
+                        void* scratch, size_t scratch_bytes, int max_row_len, int ppos, int rule, hipStream_t st, int nw = PC_STRIP_WAVES) {
+    const size_t per = strip_bytes_per_block(max_row_len, nw);
     size_t blocks = scratch ? scratch_bytes / per : 0;
     if (blocks == 0) { pc_set_error("k_nw_strip<%d>: needs %zu bytes of scratch per workgroup", W, per); return PC_ERR_ARG; }
     if (blocks > (size_t)ntasks) blocks = (size_t)ntasks;
     if (blocks > 4096) blocks = 4096;
     const size_t lines = INC16 ? (size_t)2 * ((pc_prof_rows(true) + 1) / 2) : (size_t)pc_prof_rows(false);
-    const size_t lds = (size_t)(144 + PC_STRIP_WAVES * pc_strip_wave_lds_dwords()) * 4 + lines * pc_prof_row_dwords(W, INC16) * 256;
+    const size_t lds = (size_t)(144 + nw * pc_strip_wave_lds_dwords()) * 4 + lines * pc_prof_row_dwords(W, INC16) * 256;
     hipError_t e = hipSuccess;
     switch (rule) {
-#define PC_STRIP_CASE(R) case R: e = (hipError_t)pc_strip_launch<W, R, INC16>((unsigned)blocks, lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, (uint4*)scratch, (unsigned)(max_row_len + 2)); break;
+#define PC_STRIP_CASE(R) case R: e = (hipError_t)pc_strip_launch<W, R, INC16>((unsigned)blocks, nw, lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, (uint4*)scratch, (unsigned)(max_row_len + 2)); break;
     PC_STRIP_CASE(0) PC_STRIP_CASE(1) PC_STRIP_CASE(2) PC_STRIP_CASE(3) PC_STRIP_CASE(4) PC_STRIP_CASE(5) PC_STRIP_CASE(6) PC_STRIP_CASE(7)
 #undef PC_STRIP_CASE
     default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
@@ -453,9 +460,13 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
     if (variant >= 0 && ppos && !pc_nw_ppos_systolic(variant, max_lb)) { pc_set_error("pc_launch_nw: percent-positives cannot run on variant %d for %d columns", variant, max_lb); return PC_ERR_ARG; }
     if (variant >= 0) {
         if (variant >= g_num_variants) { pc_set_error("pc_launch_nw: no variant %d", variant); return PC_ERR_ARG; }
-        if (max_lb > 64 * g_variant_w[variant]) {                                // strip-mined passes (k_nw_strip)
+        if (pc_nw_launch_is_strip(variant, max_lb, wave_mode, ppos)) {           // strip-mined passes (k_nw_strip)
             const int W = g_variant_w[variant];
-            if (ppos && W == PC_INC16_MAX_W) return launch_strip<PC_INC16_MAX_W, true>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 1, rule, st);
+            const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : PC_STRIP_WAVES;
+            if (ppos && W == PC_INC16_MAX_W) return launch_strip<PC_INC16_MAX_W, true>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 1, rule, st, nw);
+            // tasks of one row / two rows: narrow passes in one- / two-wave workgroups, whatever the class's own width
+            if (!ppos && nw == 1) return launch_strip<PC_STRIP_W_ONE_ROW, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st, 1);
+            if (!ppos && nw == 2) return launch_strip<PC_STRIP_W_TWO_ROWS, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st, 2);
             if (!ppos && W == 32) return launch_strip<32, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);
             if (!ppos && W == 48) return launch_strip<48, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);
             if (!ppos && W == 64) return launch_strip<64, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st);

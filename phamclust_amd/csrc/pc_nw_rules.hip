@@ -12,4 +12,4 @@ PC_FOR_TIER(PC_INST_TIER)
 PC_FOR_W1(PC_INST1)
 // the strip-mined kernel (column genes beyond 64 x W columns): the three wide variants, and W = 24 with the profile cell (percent-positives)
 #define PC_INST_STRIP(W, INC) template int pc_strip_launch<W, PC_RULE_A, INC> PC_STRIP_SIG; template int pc_strip_launch<W, PC_RULE_B, INC> PC_STRIP_SIG;
-PC_INST_STRIP(32, false) PC_INST_STRIP(48, false) PC_INST_STRIP(64, false) PC_INST_STRIP(24, true)
+PC_INST_STRIP(32, false) PC_INST_STRIP(48, false) PC_INST_STRIP(64, false) PC_INST_STRIP(24, true) PC_INST_STRIP(8, false) PC_INST_STRIP(12, false)

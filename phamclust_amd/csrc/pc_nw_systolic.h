@@ -574,12 +574,14 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
 // One alignment per stream: nothing follows it, so the base never steps (an alignment against 65,535 columns spans 3.4 M in
 // `hi`, more than PC_BASE_STEP), and the column state is re-initialised in every pass -- what the lanes hold from the previous
 // pass belongs to the SAME alignment and would not lose the maxima.
-// Persistent grid (pc_launch_nw sizes it by the scratch it has): a workgroup of 4 waves takes every gridDim-th task, 4 rows each;
-// all waves meet at two barriers per pass (the profile of the pass's columns is shared).
+// Persistent grid (pc_launch_nw sizes it by the scratch it has): a workgroup of NWV waves takes every gridDim-th task, one row per
+// wave; all waves meet at two barriers per pass (the profile of the pass's columns is shared).  The width is the LAUNCH's choice, not
+// the column gene's -- any W covers any length -- so tasks of one or two rows run on narrow variants in one- / two-wave workgroups
+// (PC_STRIP_W_ONE_ROW / _TWO_ROWS below), and so do such tasks of the wide variants' ordinary classes (1,537 ... 4,096 columns).
 // Limits: statistics are 16-bit fields (compare cell: la, lb <= 65,535) or 13-bit ones (profile cell, used for percent-positives:
 // lb <= 8,191).
 // ---------------------------------------------------------------------------------
-#define PC_STRIP_WAVES 4
+#define PC_STRIP_WAVES 4                                           // most waves per workgroup = rows per task (one row per wave)
 #define PC_STRIP_BND 64                                            // boundary entries a wave keeps staged (two refill windows)
 __host__ __device__ constexpr int pc_strip_wave_lds_dwords() { return 16 + PC_WIN + 4 * PC_STRIP_BND; }
 
@@ -597,9 +599,10 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
     constexpr int COLS = 64 * W;                                   // columns of a full pass
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NWV = (int)(blockDim.x >> 6);                        // waves of this workgroup: 4, or 2 / 1 for tasks of two rows / one row (narrow W)
     const int lane = threadIdx.x & 63;
     int8_t (*tab)[24] = (int8_t(*)[24])smem;
-    for (int i = threadIdx.x; i < 576; i += 64 * PC_STRIP_WAVES) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
+    for (int i = threadIdx.x; i < 576; i += 64 * NWV) tab[i / 24][i % 24] = (int8_t)(4 * (c_b62[i / 24][i % 24] + 12) + (PcTag<RULE>::tD - PcTag<RULE>::tOF));
     // the layout of the widest lanes-per-segment bucket, whatever a pass's own width: one (profile cell: two half) table(s) of 64 lanes
     constexpr int Gl = INC16 ? 32 : 64;
     constexpr uint32_t half_dw = INC16 ? (uint32_t)(((ROWS + 1) / 2) * RS * 64) : 0u;
@@ -607,9 +610,9 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
     uint32_t* wreg = smem + 144 + wv * pc_strip_wave_lds_dwords();
     uint32_t* ring = wreg + 16;                                    // [PC_WIN] staged stream entries
     uint32_t* bnd = ring + PC_WIN;                                 // [PC_STRIP_BND][4] staged boundary entries (Ho.hi, Ho.lo, E.hi, E.lo)
-    uint32_t* prof = smem + 144 + PC_STRIP_WAVES * pc_strip_wave_lds_dwords();
+    uint32_t* prof = smem + 144 + NWV * pc_strip_wave_lds_dwords();
     const uint32_t kcol = (uint32_t)(lane < Gl ? lane : lane - Gl) + (lane < Gl ? 0u : half_dw);
-    uint4* const line = spill + ((size_t)blockIdx.x * PC_STRIP_WAVES + (size_t)wv) * spill_stride;
+    uint4* const line = spill + ((size_t)blockIdx.x * (size_t)NWV + (size_t)wv) * spill_stride;
     using TG = PcTag<RULE>;
     const uint32_t K = 0x10000u;
     const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + kcol * 4u;
@@ -621,9 +624,9 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
         const int lb_all = d.gene_len[tk.gene];
         const uint8_t* __restrict__ bp_all = d.codes + d.gene_off[tk.gene];
         const int npass = (lb_all + COLS - 1) / COLS;
-        const int R = tk.end - tk.begin;                           // normally <= PC_STRIP_WAVES rows: one round of one row per wave
+        const int R = tk.end - tk.begin;                           // normally <= NWV rows: one round of one row per wave
 #pragma unroll 1
-        for (int r0 = 0; r0 < R; r0 += PC_STRIP_WAVES) {
+        for (int r0 = 0; r0 < R; r0 += NWV) {
         const int my_row = r0 + wv;
         const bool have_row = my_row < R;
         int la = 0; const uint8_t* ap = d.codes;
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
             __syncthreads();                                       // score table visible; every wave is done with the previous pass's profile
             if (in_seg) {
 #pragma unroll 1
-                for (int r = wv; r < ROWS; r += PC_STRIP_WAVES) {
+                for (int r = wv; r < ROWS; r += NWV) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q) {
                         uint32_t v = 0;
@@ -834,12 +837,17 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
 }
 
 template <int W, int RULE, bool INC16>
-int pc_strip_launch(unsigned nblocks, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks, int ntasks,
+int pc_strip_launch(unsigned nblocks, int nw, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks, int ntasks,
                     const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos, uint4* spill, unsigned spill_stride) {
-    hipLaunchKernelGGL((k_nw_strip<W, RULE, INC16>), dim3(nblocks), dim3(64 * PC_STRIP_WAVES), lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, spill, spill_stride);
+    hipLaunchKernelGGL((k_nw_strip<W, RULE, INC16>), dim3(nblocks), dim3(64 * nw), lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, spill, spill_stride);
     return (int)hipGetLastError();
 }
-#define PC_STRIP_SIG (unsigned, size_t, hipStream_t, const PcDev&, const PcTask*, int, const int32_t*, const uint32_t*, uint2*, int, uint4*, unsigned)
+#define PC_STRIP_SIG (unsigned, int, size_t, hipStream_t, const PcDev&, const PcTask*, int, const int32_t*, const uint32_t*, uint2*, int, uint4*, unsigned)
+// the strip-mined kernel's widths: the wide variants for tasks of 3-4 rows (four waves share the profile of a pass), W = 12 / W = 8
+// for tasks of two rows / one row -- the profile of a pass is 24 x W x 64 bytes of LDS PER COLUMN GENE, 49 KB at W = 32: with one
+// row to align against it a CU would hold three waves; at W = 8 it holds twelve, for 9 % more instructions per cell
+#define PC_STRIP_W_ONE_ROW 8
+#define PC_STRIP_W_TWO_ROWS 12
 
 // ---- kernels over the body -------------------------------------------------------------------------------------
 // (second launch bound = waves per SIMD the compiler must leave room for: W = 48 needs 257 registers left to itself, one more

@@ -125,9 +125,9 @@ int pc_launch_task_count(const uint32_t* start_q, const uint32_t* end_q, const P
 __device__ __forceinline__ int32_t pc_launch_class(const PcTaskPlan& tp, uint32_t base_cls, int lb, uint32_t rows) {
     int mode = PC_MODE_CLASS;
     const uint32_t nv4 = (uint32_t)tp.nvar * 4u;
-    if (tp.small_modes && base_cls < 2u * nv4) {                            // (the last base class is the general kernel: no modes)
-        const int W = tp.variant_w[(base_cls % nv4) / 4u], G = (lb + W - 1) / W;
-        const uint32_t nseg = (uint32_t)min(G > 64 ? 1 : 64 / G, 16);
+    if (tp.small_modes && base_cls < 2u * nv4 + (uint32_t)tp.n_strip) {     // (the last base class is the general kernel: no modes)
+        const int W = base_cls < 2u * nv4 ? tp.variant_w[(base_cls % nv4) / 4u] : 64, G = (lb + W - 1) / W;   // (strip-mined classes: one row per wave)
+        const uint32_t nseg = base_cls < 2u * nv4 ? (uint32_t)min(G > 64 ? 1 : 64 / G, 16) : 1u;
         mode = rows <= nseg ? PC_MODE_ONE_WAVE : rows <= 2u * nseg ? PC_MODE_TWO_WAVES : PC_MODE_CLASS;
     }
     return (int32_t)(base_cls * PC_WAVE_MODES + (uint32_t)mode);
