@@ -1405,7 +1405,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         const int64_t area = (int64_t)d.N * c->shard.nown;
         const double shared = std::max(c->avg_shared, 0.0);
         const bool counts = metric == PC_GCS || metric == PC_JC;
-        const bool s64_ok = counts ? c->max_nph < (1 << 30) : metric == PC_POCP ? c->max_ngen < (1 << 30) : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
+        const bool s64_ok = counts ? c->max_nph < (1 << 30) : metric == PC_POCP ? c->max_ngen < (1 << 16) /* two gene counts per register */ : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
         if (counts) kernel = (((double)d.Wb > 113.0 + 5.4 * shared && area >= (int64_t)3000 * 3000) ||
                               ((double)d.Wb > 60.0 + 5.4 * shared && area >= (int64_t)7000 * 7000)) ? K_SPARSE64 : K_POPC;   // (the sparse tiles gain on the popcount tiles as N grows: 5,056 phams, N = 5,000 0.172 against 0.158 ms, 10,000 0.489 against 0.545, 20,000 1.79 against 2.03)
         else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;

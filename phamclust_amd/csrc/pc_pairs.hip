@@ -712,7 +712,12 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
             lo_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_s, r); hi_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_s, r);
             lo_t[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_t, r); hi_t[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_t, r);
         }
-        int ph_s[S6_RPW][S6_B], ph_t[S6_RPW][S6_B]; uint32_t v_s[S6_RPW][S6_B], v_t[S6_RPW][S6_B];
+        // pocp keeps BOTH sides' gene counts of slot (rr, b) in one register (source's count below, target's above bit 16: the host
+        // takes this kernel for pocp only while every genome holds fewer than 65,536 genes).  With a register each, the one-batch
+        // instance needed 84 against the 80 that six waves per SIMD leave: three dwords went to scratch, and scratch stores reach
+        // HBM -- the 23 % of writes beyond the matrix that the r03 counters showed for pocp alone (WRITE_SIZE 1.97 GB for 1.60 GB)
+        constexpr bool PACKED = MODE == PCW_POCP;
+        int ph_s[S6_RPW][S6_B], ph_t[S6_RPW][S6_B]; uint32_t v_s[S6_RPW][S6_B], v_t[PACKED ? 1 : S6_RPW][PACKED ? 1 : S6_B];
 #pragma unroll
         for (int rr = 0; rr < S6_RPW; ++rr)
 #pragma unroll
@@ -724,15 +729,19 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
                     ph_t[rr][b] = it ? d.sp_pham[et] - p0 : -1; v_t[rr][b] = 1u;
                 } else {
                     const uint2 xs = is ? ent[es] : make_uint2((uint32_t)(p0 - 1), 0u), xt = it ? ent[et] : make_uint2((uint32_t)(p0 - 1), 0u);
-                    ph_s[rr][b] = (int)xs.x - p0; v_s[rr][b] = xs.y;
-                    ph_t[rr][b] = (int)xt.x - p0; v_t[rr][b] = xt.y;
+                    ph_s[rr][b] = (int)xs.x - p0; ph_t[rr][b] = (int)xt.x - p0;
+                    if constexpr (PACKED) v_s[rr][b] = xs.y | (xt.y << 16);
+                    else { v_s[rr][b] = xs.y; v_t[rr][b] = xt.y; }
                 }
             }
         // one direction: the rows of one side build the masks, the rows of the other probe them.  TO_ROW: the probing rows are
         // the accumulator rows (sources probe), else its columns (targets probe)
-        auto hit = [&](auto to_row, int r, int ph, uint32_t v, uint32_t& hs) {
+        auto hit = [&](auto to_row, auto packed, int r, int ph, uint32_t v, uint32_t& hs) {
             // pocp: the entry's gene count c adds c + 1 where the sources probe and c - 1 where the targets do (see below)
-            if constexpr (MODE == PCW_POCP) v = decltype(to_row)::value ? v + 1u : v - 1u;
+            if constexpr (MODE == PCW_POCP) {
+                if constexpr (decltype(packed)::value) v = decltype(to_row)::value ? (v & 0xffffu) : (v >> 16);
+                v = decltype(to_row)::value ? v + 1u : v - 1u;
+            }
             uint2 m = make_uint2(0u, 0u);
             if (ph >= 0) m = *(const uint2*)&colmask[2 * ph];
             const int pc = __popc(m.x) + __popc(m.y);
@@ -774,13 +783,13 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
                 const int r = wave + S6_WAVES * rr;
                 uint32_t hs = 0;
 #pragma unroll
-                for (int b = 0; b < S6_B; ++b) hit(to_row, r, qph[rr][b], qv[rr][b], hs);
+                for (int b = 0; b < S6_B; ++b) hit(to_row, std::integral_constant<bool, PACKED>{}, r, qph[rr][b], qv[rr][b], hs);
                 for (uint32_t e0 = qlo[rr] + 64u * S6_B; e0 < qhi[rr]; e0 += 64u) {
                     const uint32_t e = e0 + (uint32_t)lane;
                     const bool in = e < qhi[rr];
                     uint2 x = make_uint2((uint32_t)(p0 - 1), 0u);
                     if (in) { if constexpr (COUNT) x = make_uint2((uint32_t)d.sp_pham[e], 1u); else x = ent[e]; }
-                    hit(to_row, r, (MODE == PCW_POCP && !decltype(to_row)::value && x.y <= 1u) ? -1 : (int)x.x - p0, x.y, hs);
+                    hit(to_row, std::false_type{}, r, (MODE == PCW_POCP && !decltype(to_row)::value && x.y <= 1u) ? -1 : (int)x.x - p0, x.y, hs);
                 }
                 if (hs) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + lane : lane * S6_LD + r], hs);
             }
@@ -796,9 +805,9 @@ __global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_til
 #pragma unroll
             for (int rr = 0; rr < S6_RPW; ++rr)
 #pragma unroll
-                for (int b = 0; b < S6_B; ++b) if (v_t[rr][b] <= 1u) ph_t[rr][b] = -1;       // (the targets' masks are not built again)
-            direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);
-        } else direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);      // the other way round
+                for (int b = 0; b < S6_B; ++b) if ((v_s[rr][b] >> 16) <= 1u) ph_t[rr][b] = -1;       // (the targets' masks are not built again)
+            direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_s, lo_t, hi_t);                   // (v_s: both sides' counts, packed)
+        } else if constexpr (!PACKED) direction(std::false_type{}, ph_s, lo_s, hi_s, ph_t, v_t, lo_t, hi_t);      // the other way round
     }
     // finish: 4,096 pairs, 8 per thread; consecutive lanes run along the output's contiguous direction
 #pragma unroll 4

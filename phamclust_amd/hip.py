@@ -160,6 +160,9 @@ class BorrowedArray(np.lib.mixins.NDArrayOperatorsMixin):
         got = self._view[item]
         return BorrowedArray(got, None, self._root) if isinstance(got, np.ndarray) and got.base is not None else got
 
+    def __setitem__(self, item, value):                       # lent memory is the context's: read-only, like the view under it
+        raise ValueError("assignment destination is read-only (a borrowed result of Context.fill)")
+
     def __iter__(self):
         self._check_loan()
         return iter(self._view)

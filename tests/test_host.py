@@ -305,6 +305,8 @@ def test_borrowed_array_guards_every_numpy_route():
     part = lent[2:5]                                          # a slice shares the loan
     assert lent.shape == (12,) and len(part) == 3 and lent.dtype == np.float64 and float(lent[3]) == 3.0
     assert type(np.asarray(lent)) is np.ndarray and np.array_equal(lent, base) and list(part) == [2.0, 3.0, 4.0]
+    with pytest.raises(ValueError):
+        lent[0] = 0.5
     assert float(np.sum(lent)) == 66.0 and type(lent + 1) is np.ndarray and (lent + 1)[0] == 1.0
     assert type(np.ascontiguousarray(lent)) is np.ndarray and np.concatenate([lent, part]).shape == (15,)
     assert float(part.max()) == 4.0 and float(np.dot(lent, lent)) == float(np.dot(base, base))
