@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PC_VERSION 140   /* 0.3.0: two-part upload, memory-bounded (chunked) aai / peq fills */
+#define PC_VERSION 150   /* 0.4.0: strip-mined passes for long column genes, tier launches, small-task workgroups */
 
 typedef enum {
     PC_OK = 0,
@@ -230,6 +230,36 @@ int pc_last_set_kernel(const pc_ctx* ctx);
 /* Test hook: the device implementation of Python's round(x, 6) (the rounding every metric
  * returns through, e.g. metrics.py:50-53) applied to n host doubles in [0, 2^20). */
 int pc_round6_probe(pc_ctx* ctx, const double* in, double* out, int64_t n);
+
+/*
+ * Environment switches of the library, all of them (the product needs none: defaults are what profiles/ measures).
+ *
+ *   read at pc_ctx_create
+ *     PC_TIE_RULE=0..7          row of the aligner's tie-rule table (pc_set_tie_rule overrides it per context)
+ *     PC_PLAN_BYTES=n           HBM one chunk of an aai / peq fill's plan may take (pc_set_plan_budget overrides it)
+ *     PC_ALIGN_STREAMS=1..16    streams the alignment launches of a fill are dealt to (8)
+ *   read once per process
+ *     PC_NO_ROCTX               do not look for libroctx64 (no marker ranges)
+ *     PC_UPLOAD_TIMING          per-phase wall times of pc_upload on stderr
+ *     PC_RAW_STAGE_MAX=n        largest residue set staged through page-locked memory (512 MB; beyond: copied from the caller's pages)
+ *   tuning / A-B switches (read once per process; every setting gives the same matrix, tests/ hold them to that)
+ *     PC_TASK_BUDGET=n          cell slots per row stream of an alignment task (49,152)
+ *     PC_CHOOSE_C0, PC_CHOOSE_C1, PC_CHOOSE_CELL   constants of the variant chooser's cost model (0.3, 0.535, 0.94)
+ *     PC_REMAINDER=0, PC_REMAINDER_MARGIN=x        no narrower variant for a bucket's left-over rows / its margin (0.7)
+ *     PC_INC16=0|1              the 11- / 10-instruction DP cell wherever both are compiled
+ *     PC_SMALL_MODES=0          no one- / two-wave workgroups for tasks of few rows;  PC_SMALL_LAUNCH_MIN=n  fewest such tasks that get a launch of their own (192)
+ *     PC_FUSE=0                 one launch per launch class instead of one per register tier
+ *     PC_STRIP=0                column genes beyond 4,096 residues on the one-lane-per-alignment kernel instead of strip-mined passes
+ *     PC_ALIGN_ORDER=size       largest class first instead of longest column genes first
+ *   read per fill / per launch (the tests switch them between calls)
+ *     PC_POPC_TILE=32|64        force the word-split 32 x 32 / the 64 x 64 popcount tile kernel
+ *     PC_SET_KERNEL=popc|sparse|sparse64|walker    force a kernel family for gcs / jc / pocp / af where it exists for the metric
+ *     PC_S64_CHUNKS=n           at least n mask chunks in the 64 x 64 sparse tile kernel
+ *   only in libphamclust_hip_hooks.so (compiled with -DPC_TEST_HOOKS; pc_test_hooks() == 1)
+ *     PC_FAKE_OOM_ABOVE=n       device allocations above n bytes made while a fill is planning fail (fault injection)
+ * The Python package adds PHAMCLUST_DEVICE, PHAMCLUST_DIST_BACKEND, PHAMCLUST_DIST_MODE, PHAMCLUST_DIST_TIMEOUT_S, PHAMCLUST_LAUNCH_COST_S,
+ * PHAMCLUST_FORCE_GPUS, PHAMCLUST_NO_TORCH and PHAMCLUST_NATIVE_VARIANT.
+ */
 
 #ifdef __cplusplus
 }

@@ -247,8 +247,6 @@ static bool mode_inc16(int W, int G, int cell_mode) {
 static int waves_for(int W, int G, int cell_mode) {
     const int Gb = pc_nw_g_bucket(G), top = pc_max_waves(W);
     const bool inc16 = mode_inc16(W, G, cell_mode);
-    static const int force_waves = getenv("PC_FORCE_WAVES") ? atoi(getenv("PC_FORCE_WAVES")) : 0;   // experiment: every workgroup with this many waves
-    if (force_waves > 0) return force_waves < top ? force_waves : top;
     if (!inc16) return PC_MIN_WAVES;
     for (int nw = PC_MIN_WAVES; nw <= top; nw *= 2)
         if ((int)((size_t)160 * 1024 / systolic_lds_bytes(W, Gb, nw, inc16)) * nw >= 16) return nw;

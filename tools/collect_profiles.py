@@ -8,7 +8,8 @@
   <tag>_counters.json                      PMC sums per kernel family and per fill: HBM traffic (FETCH_SIZE x2 on gfx950,
                                            WRITE_SIZE, separate passes), VALU instructions per DP cell, clock
   traffic.json                             entry stamped with the hash of the kernel sources it was measured on
-usage: collect_profiles.py <tag>
+usage: collect_profiles.py <tag> [<out dir under profiles/, e.g. r04/final>]
+With an out dir the records drop the tag prefix: profiles/r04/final/bench_peq5000.json, ... (one directory per round, r04 on).
 """
 import collections
 import csv
@@ -24,6 +25,17 @@ sys.path.insert(0, REPO)
 tag = sys.argv[1]
 G = os.path.join(REPO, "gpurun_out")
 P = os.path.join(REPO, "profiles")
+OUT_DIR = sys.argv[2] if len(sys.argv) > 2 else ""
+os.makedirs(os.path.join(P, OUT_DIR), exist_ok=True)
+
+
+def rec(name):
+    """Tracked path of record `name`: profiles/<tag>_<name>, or profiles/<out dir>/<name>."""
+    return os.path.join(P, OUT_DIR, name) if OUT_DIR else os.path.join(P, f"{tag}_{name}")
+
+
+def rec_rel(name):
+    return os.path.relpath(rec(name), REPO)
 
 
 def find(sub, suffix):
@@ -68,14 +80,14 @@ line = None
 bp = os.path.join(G, f"{tag}_bench_peq5000.json")
 if os.path.exists(bp):
     line = json.loads([l for l in open(bp).read().splitlines() if l.startswith("{")][-1])
-    shutil.copy(bp, os.path.join(P, f"{tag}_bench_peq5000.json"))
-for sub, dst in (("trace_peq", f"{tag}_bench_peq5000_kernel_stats.csv"), ("trace_set", f"{tag}_set_metrics_kernel_stats.csv")):
+    shutil.copy(bp, rec("bench_peq5000.json"))
+for sub, dst in (("trace_peq", "bench_peq5000_kernel_stats.csv"), ("trace_set", "set_metrics_kernel_stats.csv")):
     path = find(sub, "kernel_stats.csv")
     if path:
-        shutil.copy(path, os.path.join(P, dst))
+        shutil.copy(path, rec(dst))
 sp = os.path.join(G, f"{tag}_set_metric_sweep.json")
 if os.path.exists(sp):
-    shutil.copy(sp, os.path.join(P, f"{tag}_set_metric_sweep.json"))
+    shutil.copy(sp, rec("set_metric_sweep.json"))
 
 out = {"tag": tag, "git_head_when_collected": git_head(), "kernel_source_hash": src_hash,
        "how": "tools/profile_round.sh: rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*/GRBM), each around "
@@ -103,7 +115,7 @@ if fetch and write:
         doc["entries"] = [e for e in doc["entries"] if not (e["workload"] == "synth(5000,5000) -m peq" and e["n_gpus"] == 1)]
         doc["entries"].append({"workload": "synth(5000,5000) -m peq", "n_gpus": 1, "traffic_bytes_per_fill": int(nw["traffic_bytes"]),
                                "fetch_raw_bytes": int(nw["fetch_raw_bytes"]), "write_bytes": int(nw["write_bytes"]),
-                               "source": f"profiles/{tag}_counters.json", "kernel_source_hash": src_hash, "git_head_when_collected": git_head()})
+                               "source": rec_rel("counters.json"), "kernel_source_hash": src_hash, "git_head_when_collected": git_head()})
         json.dump(doc, open(tj, "w"), indent=1)
 if valu:
     v = valu.get("k_nw_systolic", {})
@@ -124,5 +136,5 @@ if sf and sw:
         per[k] = {"launches": n, "fetch_corrected_bytes_per_launch": 2 * f / n, "write_bytes_per_launch": w / max(swc.get(k, 1), 1),
                   "traffic_bytes_per_launch": 2 * f / n + w / max(swc.get(k, 1), 1)}
     out["set_metrics_n20000_hbm_traffic"] = {"kernels": per, "algorithmic_bytes_per_fill": 20000 * 79 * 8 + 16 * 20000 + 8 * (20000 * 19999 // 2)}
-json.dump(out, open(os.path.join(P, f"{tag}_counters.json"), "w"), indent=1)
+json.dump(out, open(rec("counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
