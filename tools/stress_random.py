@@ -6,7 +6,11 @@ r01: seed 4242, 1,500 collections, 9,000 fills, 0 mismatches; seed 20261004, 4,0
 r02 (64-bit lexicographic-max cell, all 8 rules): see profiles/r02_stress.txt.
 r03: every collection additionally draws a plan budget (aai / peq fills in one piece or in many chunks), a two-part or a full
 upload, both popcount tile kernels (PC_POPC_TILE, read per launch), every pocp / af kernel (PC_SET_KERNEL) and, every fourth one, a shard of a 2- or 3-rank deal compared with
-the same pairs of the unsharded matrix: see profiles/r03_stress.txt."""
+the same pairs of the unsharded matrix: see profiles/r03_stress.txt.
+r04: one collection in twelve holds genes of 4,100-8,100 residues (strip-mined passes on the wide and the narrow variants, the
+percent-positives passes), PC_S64_CHUNKS is drawn per collection, and buckets of one or
+two rows -- most of what these tiny collections hold -- take the one- / two-wave workgroups and the tier launches: see
+profiles/r04/final/stress.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,8 +26,11 @@ bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
     n_genomes, n_phams = int(rng.integers(2, 14)), int(rng.integers(1, 9))
     maxlen = int(rng.choice([12, 90, 400, 1500]))
+    long_genes = trial % 12 == 11                            # r04: column genes beyond the widest variant's 4,096 columns
     alpha = few if rng.random() < 0.4 else letters
     pool = ["".join(alpha[rng.integers(0, alpha.size, int(rng.integers(1, maxlen + 1)))]) for _ in range(int(rng.integers(1, 10)))]
+    if long_genes:
+        pool += ["".join(alpha[rng.integers(0, alpha.size, int(rng.integers(4100, 8101)))]) for _ in range(2)]
     rule = int(rng.integers(0, 8))
     ctx.set_tie_rule(rule); O.set_tie_rule(rule)
     genomes = []
@@ -42,6 +49,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
     ctx.set_plan_budget(int(rng.choice([0, 56, 56 * 7, 56 * 60, 56 * 2000])))   # 0: automatic; tiny: one target genome per chunk
     os.environ["PC_POPC_TILE"] = str(rng.choice(["32", "64"]))
     os.environ["PC_SET_KERNEL"] = str(rng.choice(["popc", "sparse", "sparse64", "walker"]))   # pocp / af kernel, read per fill
+    os.environ["PC_S64_CHUNKS"] = str(rng.choice(["1", "2", "3"]))
     for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
         got = ctx.fill(metric, as_distance=bool(trial & 1))
         want = O.fill(packed, metric, as_distance=bool(trial & 1))
