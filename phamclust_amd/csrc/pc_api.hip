@@ -1382,7 +1382,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     as_distance = as_distance ? 1 : 0;
     PC_HIP(hipEventRecord(c->ev[0], st));
 
-    // Which kernel fills a set metric (measured crossovers, `profiles/r03_p_sparse64_record.txt`, `r03_z_pocp_kernel_by_density.txt`;
+    // Which kernel fills a set metric (measured crossovers, `profiles/r03/experiments/p_sparse64_record.txt`, `r03_z_pocp_kernel_by_density.txt`;
     // PC_SET_KERNEL = popc | sparse | sparse64 | walker forces one where it exists, for A/B runs and for the tests that keep every
     // one of them honest):
     //   gcs, jc          popcount tiles; a collection of many phams (long bitmap rows, few of them shared): the 64 x 64 sparse tile

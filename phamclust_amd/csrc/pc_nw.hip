@@ -128,7 +128,7 @@ int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants ||
 // Variant for a column gene of lb residues.  Time per row step ~ (W + c0 + c1 nseg) cell-equivalents (x 1.014 at
 // W = 22, x 1.022 at W = 24: three waves per SIMD), during which a wave retires nseg rows of lb cells; c1 = 0.535
 // from a least-squares fit to measured kernel-only GCUPS of every variant over L = 60..1200
-// (profiles/r01_l_variant_gcups.txt), c0 = 0.3 after the step prologue shrank to ~12 instructions (end-to-end
+// (profiles/r01/experiments/l_variant_gcups.txt), c0 = 0.3 after the step prologue shrank to ~12 instructions (end-to-end
 // sweep: the fill time is flat within 1 % over c0 = 0.3..1.0).  The nseg term stands for what short sequences pay
 // per alignment and per task (virtual row, pipeline fill, profile build).  Minimise cost per retired row over the
 // variants whose 64*W columns cover lb.  PC_CHOOSE_C0 / PC_CHOOSE_C1 override the constants for tuning runs.
@@ -171,7 +171,7 @@ int pc_nw_choose_variant(int lb) {
         if (G > 64) continue;
         int nseg = 64 / G; if (nseg > 16) nseg = 16;
         // W >= 32 exist for very long column genes (up to 4,096 residues).  They run at 2 or 1 waves per SIMD yet
-        // measure 1.9-2.2 TCUPS at full lane use (profiles/r01_o_wide_variant_gcups.txt): one wave can keep its
+        // measure 1.9-2.2 TCUPS at full lane use (profiles/r01/experiments/o_wide_variant_gcups.txt): one wave can keep its
         // SIMD's VALU busy, so the penalty is small
         const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
         static const double c0 = getenv("PC_CHOOSE_C0") ? atof(getenv("PC_CHOOSE_C0")) : 0.3;
@@ -223,7 +223,7 @@ static size_t systolic_lds_bytes(int W, int G, int nw, bool inc16, bool any_buck
 // Lanes-per-segment bucket of a launch class (pc_api.hip's classes use the same bounds): every column gene of a launch
 // lies in one bucket, so launch, task sizes and LDS agree on the waves per workgroup without passing it around
 int pc_nw_g_bucket(int G) { return G <= 8 ? 8 : (G <= 16 ? 16 : (G <= 32 ? 32 : 64)); }
-// Which cell a launch class runs (measured per class with the launches serialised, profiles/r02_l_class_times.txt):
+// Which cell a launch class runs (measured per class with the launches serialised, profiles/r02/experiments/l_class_times.txt):
 // the 16-bit increment profile wins 5-7 % where four workgroups still fit a CU beside it (segments of up to 16 lanes)
 // and 3-5 % with 8-wave workgroups on segments of up to 32 lanes for W = 11..19 (W <= 9: -15..-40 %, short strips; W = 20: nothing; W = 24: -6 % in
 // either bucket, its profile needs 8-wave groups even at 16 lanes); with

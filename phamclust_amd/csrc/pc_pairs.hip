@@ -90,7 +90,7 @@ __device__ __forceinline__ int64_t pc_out_index(const PcDev& d, const PcShard& s
 // XCD-aware tile order for the pair kernels (1-D grids).  The dispatcher hands workgroups to the 8 XCDs round-robin by
 // flat id, and every XCD has its own 4 MiB L2.  With a plain 2-D grid each XCD sees tiles from everywhere and streams
 // the whole bitmap (plus rank and entry tables) through its L2 again and again: at N = 20,000 the popcount kernel
-// fetched 2.4 GB for a 12.6 MB bitmap, the walker 11 GB (profiles/r02_c_counters.json).  Here tiles are grouped into
+// fetched 2.4 GB for a 12.6 MB bitmap, the walker 11 GB (profiles/r02/experiments/c_counters.json).  Here tiles are grouped into
 // super-tiles of up to 8 x 8 tiles and consecutive workgroups of one XCD walk one super-tile, so the ~100 workgroups
 // resident on an XCD share the rows of one or two super-tiles (0.29 GB and 1.3 GB after the change).  Affinity only:
 // nothing depends on where a workgroup really runs.
@@ -504,7 +504,7 @@ int pc_launch_set_popc(const PcDev& d, const PcShard& sh, int metric, int as_dis
 // ---------------------------------------------------------------------------------
 // K2 for SMALL matrices: pocp / af as a SPARSE bitset intersection (r03).  Used below ~3,500 genomes, where it beats the
 // shared-pham walker (N = 2,000: 0.122 against 0.184 ms); above, the walker stays (N = 20,000: 5.6 against 7.1 ms --
-// where the time goes: `profiles/r03_c_sparse_tile_experiment.txt`: the divergent per-bit add loops 3.6 ms, mask build + reads
+// where the time goes: `profiles/r03/experiments/c_sparse_tile_experiment.txt`: the divergent per-bit add loops 3.6 ms, mask build + reads
 // 2.9 ms, everything else, fp64 epilogue included, 0.7 ms).
 //
 // A genome holds ~100 of the P = 5,000 phams, a pair shares ~3 of them, and pocp / af need a value per SHARED pham
@@ -637,7 +637,7 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 // ---------------------------------------------------------------------------------
 // K2 for LARGE matrices (r03): the sparse formulation again, on 64 x 64 tiles with row-per-wave probes.
 //
-// What kept the 32 x 32 kernel behind the walker at N = 20,000 (profiles/r03_c_sparse_tile_experiment.txt): a tile pays for
+// What kept the 32 x 32 kernel behind the walker at N = 20,000 (profiles/r03/experiments/c_sparse_tile_experiment.txt): a tile pays for
 // 4 x 32 entry lists (build + probe, both directions) whatever its 1,024 pairs share, and its per-bit add loops diverge --
 // most probes of a source row hit no target or one, a few (phams of the target cluster's pool) hit twenty, and a wave
 // runs the longest loop of its 64 lanes.  Here

@@ -9,7 +9,7 @@ on the same synth(N, 5000) presence matrix, against the product's popcount kerne
 a lower bound for an MFMA formulation: it leaves an N x N int32 matrix in HBM -- both triangles -- that still needs the fp64
 epilogue (division, 1 - x, round(., 6)) and the condensed store, which k_set_popc does in the same pass.
 
-    python tools/mfma_set_probe.py [--sizes 2000,5000,20000] [--out profiles/r03_mfma_set_probe.json]
+    python tools/mfma_set_probe.py [--sizes 2000,5000,20000] [--out profiles/r03/experiments/mfma_set_probe.json]
 """
 import argparse
 import json

@@ -35,6 +35,7 @@ pat_tag = re.compile(r"profiles/(r0\d)_([a-z0-9]+)_")
 count = 0
 for root, dirs, files in os.walk(REPO):
     dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__", ".hypothesis", ".pytest_cache", "golden")]
+    files = [f for f in files if not (root == REPO and f.startswith(("BENCH_", "VERDICT", "ADVICE", "GPUTEST_", "SCALE_", "MULTICHIP_", "SURVEY", "BASELINE")))]   # the driver's and the judge's files are not ours to edit
     for f in files:
         if not f.endswith((".py", ".md", ".hip", ".h", ".c", ".sh", ".json")) or (root == PROF or root.startswith(PROF + os.sep)) and not f.endswith(".md"):
             continue

@@ -3,10 +3,10 @@
 sequences, odd residues, tie-heavy 3-letter sequences, lengths up to 1,500), every collection under a randomly chosen
 row of the tie-rule table (kernel and oracle switched together): `python tools/stress_random.py SEED TRIALS`.
 r01: seed 4242, 1,500 collections, 9,000 fills, 0 mismatches; seed 20261004, 4,000 collections, 24,000 fills, 0 mismatches.
-r02 (64-bit lexicographic-max cell, all 8 rules): see profiles/r02_stress.txt.
+r02 (64-bit lexicographic-max cell, all 8 rules): see profiles/r02/final/stress.txt.
 r03: every collection additionally draws a plan budget (aai / peq fills in one piece or in many chunks), a two-part or a full
 upload, both popcount tile kernels (PC_POPC_TILE, read per launch), every pocp / af kernel (PC_SET_KERNEL) and, every fourth one, a shard of a 2- or 3-rank deal compared with
-the same pairs of the unsharded matrix: see profiles/r03_stress.txt.
+the same pairs of the unsharded matrix: see profiles/r03/final/stress.txt.
 r04: one collection in twelve holds genes of 4,100-8,100 residues (strip-mined passes on the wide and the narrow variants, the
 percent-positives passes), PC_S64_CHUNKS is drawn per collection, and buckets of one or
 two rows -- most of what these tiny collections hold -- take the one- / two-wave workgroups and the tier launches: see
