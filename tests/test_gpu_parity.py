@@ -1535,3 +1535,34 @@ def test_real_collection_shape_full_matrix(gpu_ctx, native_built):
                 assert np.array_equal(gpu_ctx.fill(metric), O.fill(pk, metric)), (kernel, metric)
     finally:
         os.environ.pop("PC_SET_KERNEL", None)
+
+
+def test_launch_policy_switches_change_no_value(native_built):
+    """The r04 launch machinery -- tier launches (PC_FUSE), one- / two-wave workgroups for small tasks (PC_SMALL_MODES, fold
+    threshold PC_SMALL_LAUNCH_MIN), strip-mined passes (PC_STRIP) -- is policy: every setting must give the oracle's matrix
+    (metrics.py:178-253) and differ only in how many launches it takes.  The switches are read once per process, so each
+    setting runs in a process of its own, on a collection with small and large buckets and a few genes beyond 4,096 residues."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from phamclust_amd import hip
+from phamclust_amd.synth import synth_real
+from oracle import oracle as O
+pk = synth_real(120, seed=12)
+assert (np.diff(pk.seq_off) > 4096).any()
+with hip.Context(0) as ctx:
+    ctx.upload(pk)
+    got, st = ctx.fill("peq", want_stats=True)
+    assert np.array_equal(got, O.fill(pk, "peq")), "peq differs from the oracle"
+    print(json.dumps({"launches": st["n_align_launches"], "tasks": st["n_tasks"]}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for name, env in (("default", {}), ("per_class", {"PC_FUSE": "0", "PC_SMALL_LAUNCH_MIN": "1"}), ("no_modes_no_strip", {"PC_SMALL_MODES": "0", "PC_STRIP": "0"})):
+        run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, (name, run.stdout[-1500:], run.stderr[-3000:])
+        seen[name] = json.loads(run.stdout.strip().splitlines()[-1])
+    assert seen["default"]["tasks"] == seen["per_class"]["tasks"] and seen["default"]["launches"] < seen["per_class"]["launches"], seen
