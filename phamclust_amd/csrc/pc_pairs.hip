@@ -669,8 +669,15 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 // S6_B: 64-entry batches of a row held in registers -- 2 when one mask chunk holds all phams (a row's ~100 entries), 1 when the
 // phams take several chunks (a row then has a few dozen entries per chunk; half the loads and probe steps, and registers for a
 // third workgroup per CU: the launch bound asks for six waves per SIMD there)
+// Waves per SIMD the instances are compiled for.  The counting mode's one-batch instance takes 59 registers: eight waves per SIMD,
+// FOUR workgroups per CU beside 4 x 38.6 KB of LDS (r04: N = 20,000 jc 1.78 -> 1.56 ms -- a tile is a chain of latencies, three
+// global-load rounds and five barriers, so what a CU overlaps is what counts).  af / pocp need 78-79 and stay at six (three
+// workgroups); what was tried to get them to 64 and was slower or spilled (profiles/r04/experiments/sparse64_occupancy.txt):
+// 16-wave tiles with four rows per wave (64 registers with 9-12 dwords of scratch: pocp 2.38 -> 2.87 ms, af 2.58 -> 2.99), one
+// register per entry (13 bits of id, 19 of value: the compiler unpacks up front or spills 17-31 dwords under the 64 bound).
+__host__ __device__ constexpr int pc_s6_waves_per_simd(int mode, int batches) { return batches != 1 ? 4 : (mode >= PCW_SPARSE_GCS ? 8 : 6); }
 template <int MODE, int S6_B>
-__global__ __launch_bounds__(64 * S6_WAVES, S6_B == 1 ? 6 : 4) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
+__global__ __launch_bounds__(64 * S6_WAVES, pc_s6_waves_per_simd(MODE, S6_B)) void k_sparse_tile64(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int CH, unsigned n_units) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
     uint32_t* colmask = sp_lds;                                                    // [CH][2]
     uint32_t* acc = sp_lds + 2 * CH;                                               // [64 sources][65]
