@@ -1407,7 +1407,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         const bool counts = metric == PC_GCS || metric == PC_JC;
         const bool s64_ok = counts ? c->max_nph < (1 << 30) : metric == PC_POCP ? c->max_ngen < (1 << 16) /* two gene counts per register */ : (c->min_gene_len >= 1 && c->max_tlen < (int64_t)1 << 31);
         if (counts) kernel = (((double)d.Wb > 113.0 + 5.4 * shared && area >= (int64_t)3000 * 3000) ||
-                              ((double)d.Wb > 60.0 + 5.4 * shared && area >= (int64_t)7000 * 7000)) ? K_SPARSE64 : K_POPC;   // (the sparse tiles gain on the popcount tiles as N grows: 5,056 phams, N = 5,000 0.172 against 0.158 ms, 10,000 0.489 against 0.545, 20,000 1.79 against 2.03)
+                              ((double)d.Wb > 60.0 + 5.4 * shared && area >= (int64_t)6000 * 6000)) ? K_SPARSE64 : K_POPC;   // (the sparse tiles gain on the popcount tiles as N grows: 5,056 phams, r04 with four workgroups per CU: N = 5,000 0.162 against 0.157 ms, 6,000 0.218 / 0.219, 7,000 0.258 / 0.282, 20,000 1.56 / 2.03)
         else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
