@@ -14,9 +14,10 @@
  * aborts cross this boundary: every function returns 0 or a negative pc_status and
  * leaves a message for pc_last_error().
  *
- * Threading: one host thread drives one pc_ctx; one pc_ctx drives one GPU
- * (one process per GPU; multi-GPU = one ctx per rank + pc_set_shard, the exchange is the
- * caller's single RCCL gather of the shard buffers).
+ * Threading: one host thread drives one pc_ctx; one pc_ctx drives one GPU.  Multi-GPU, two ways:
+ * one process per GPU (one ctx per rank + pc_set_shard*, the exchange is the caller's single
+ * RCCL gather of the shard buffers), or one process for all of them (pc_multi_*: the library
+ * owns a ctx and a host thread per device and does the exchange itself).
  */
 #ifndef PHAMCLUST_HIP_H
 #define PHAMCLUST_HIP_H
@@ -189,6 +190,31 @@ int pc_assemble_dev(pc_ctx* ctx, const void* gathered_dev, int world, void* out_
 int pc_plan_dev(pc_ctx* ctx, int metric, void* stream, pc_stats* stats);
 int pc_align_slice_dev(pc_ctx* ctx, int slice_rank, int slice_world, void* res_dev, void* stream, pc_stats* stats);
 int pc_reduce_dev(pc_ctx* ctx, int metric, int as_distance, const void* res_dev, void* out_condensed_dev, void* stream);
+
+/*
+ * One process, several GPUs -- what SURVEY 8(b) specified as pc_ctx_create(out, device_ids, n_dev): the reference spreads the pair
+ * list over `cpus` worker processes inside matrix_de_novo (matrix.py:471-493); this spreads it over the GPUs of the node from ONE
+ * process, the library owning a context per device and a host thread per device for the length of each call.  Same static shard as
+ * the one-process-per-GPU route above (the cost-balanced deal of the target genomes), same single exchange -- every device copies
+ * its shard into the root's gather buffer, device to device (peer copies over xGMI) -- same device-side assembly; nothing to launch,
+ * no interpreter, framework import or process group per GPU (those cost ~2.5 s per job: profiles/r04/final/launch_cost.txt).
+ * device_ids[0] is the root (it delivers the matrix); an id may repeat (several contexts on one GPU: how the tests rehearse this on
+ * a one-GPU box).  One host thread calls in.
+ *   pc_multi_upload(m, g, with_residues)  every device, in parallel; with_residues = 0: what the four set metrics need
+ *   pc_multi_upload_residues(m, g)        what aai / peq need on top (g: the same packed genomes)
+ *   pc_multi_fill_borrow(...)             the whole matrix: *out_host -> f64[N(N-1)/2], scipy condensed order, in page-locked memory
+ *                                         of the root context, valid until the next fill or upload; stats: NULL or an array of
+ *                                         pc_multi_devices(m) entries (each device's own fill); exchange_ms / assemble_ms: NULL or
+ *                                         the slowest device's copy to the root / the root's permutation (HIP events)
+ */
+typedef struct pc_multi pc_multi;
+int pc_multi_create(pc_multi** out, const int* device_ids, int n_dev);
+void pc_multi_destroy(pc_multi* m);
+int pc_multi_devices(const pc_multi* m);
+int pc_multi_upload(pc_multi* m, const pc_packed* genomes, int with_residues);
+int pc_multi_upload_residues(pc_multi* m, const pc_packed* genomes);
+int pc_multi_set_tie_rule(pc_multi* m, int rule);
+int pc_multi_fill_borrow(pc_multi* m, int metric, int as_distance, const double** out_host, pc_stats* stats, float* exchange_ms, float* assemble_ms);
 
 /*
  * Test hook for the alignment kernels (replaces parasail.nw_trace_diag_16 +

@@ -21,6 +21,7 @@
 #include <memory>
 #include <new>
 #include <numeric>
+#include <string>
 #include <thread>
 #include <mutex>
 #include <vector>
@@ -1766,4 +1767,177 @@ extern "C" int pc_round6_probe(pc_ctx* c, const double* in, double* out, int64_t
     a.release(); b.release();
     if (e != hipSuccess) { pc_set_error("pc_round6_probe: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One process, several GPUs ("pc_ctx_create(out, device_ids, n_dev) ... the library owns one host thread per
+// GPU ... invisible to Python").  The torch.distributed route (one PROCESS per GPU, pc_set_shard* + the caller's RCCL gather) costs
+// ~2.5 s before the first pair -- a launcher, an interpreter, a torch import and a process group per rank
+// (profiles/r04/final/launch_cost.txt) -- against a 0.6-s fill at N = 5,000.  pc_multi_* does the same static shard with none of
+// that: one pc_ctx per device, a host thread per device for the length of a call, every device uploaded in parallel, each filling
+// the pairs of the target genomes it is dealt (the cost-balanced deal: deterministic, so every context arrives at the same
+// partition by itself), and ONE exchange -- every device copies its shard to the root's gather buffer, device to device (peer
+// copies: xGMI between the GPUs of a node) -- before the root permutes the shards into condensed order and delivers them to the
+// host.  The reference spreads the same pair list over `cpus` worker processes (matrix.py:471-493).
+// ---------------------------------------------------------------------------------------------------------------------
+struct pc_multi {
+    std::vector<pc_ctx*> ctx;               // ctx[0] is the root: it holds the gather buffer, the assembled matrix and the pinned result
+    DevBuf b_gather;                        // root device: world x stride doubles
+    std::vector<DevBuf> b_shard;            // device r: its shard, stride doubles (allocated on that device)
+    bool uploaded = false, residues = false;
+};
+
+namespace {
+// fn(rank) on one host thread per device; the first failure (status, message) is re-raised on the calling thread
+template <class F> int multi_each(pc_multi* m, F fn) {
+    const int n = (int)m->ctx.size();
+    std::vector<int> rc(n, PC_OK);
+    std::vector<std::string> msg(n);
+    auto work = [&](int r) { rc[r] = fn(r); if (rc[r] != PC_OK) msg[r] = pc_last_error(); };
+    if (n == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n; ++r) th.emplace_back(work, r);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < n; ++r) if (rc[r] != PC_OK) { pc_set_error("device %d (rank %d of %d): %s", m->ctx[r]->device, r, n, msg[r].c_str()); return rc[r]; }
+    return PC_OK;
+}
+}  // namespace
+
+extern "C" int pc_multi_create(pc_multi** out, const int* device_ids, int n_dev) {
+    if (!out) { pc_set_error("pc_multi_create: out is NULL"); return PC_ERR_ARG; }
+    *out = nullptr;
+    if (!device_ids || n_dev < 1 || n_dev > 64) { pc_set_error("pc_multi_create: %d devices", n_dev); return PC_ERR_ARG; }
+    pc_multi* m = new (std::nothrow) pc_multi();
+    if (!m) { pc_set_error("out of host memory"); return PC_ERR_ARG; }
+    m->b_shard.resize((size_t)n_dev);
+    for (int r = 0; r < n_dev; ++r) {
+        pc_ctx* c = nullptr;
+        const int rc = pc_ctx_create(&c, device_ids[r]);
+        if (rc != PC_OK) { pc_multi_destroy(m); return rc; }
+        m->ctx.push_back(c);
+    }
+    // peer access root <- every other device where the hardware offers it (the copies work without, staged by the runtime)
+    for (int r = 1; r < n_dev; ++r) {
+        if (m->ctx[r]->device == m->ctx[0]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, m->ctx[r]->device, m->ctx[0]->device) == hipSuccess && can) {
+            PcDeviceGuard guard(m->ctx[r]->device);
+            const hipError_t e = hipDeviceEnablePeerAccess(m->ctx[0]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else (void)hipGetLastError();
+        } else (void)hipGetLastError();
+    }
+    *out = m;
+    return PC_OK;
+}
+
+extern "C" void pc_multi_destroy(pc_multi* m) {
+    if (!m) return;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        if (!m->ctx[r]) continue;
+        { PcDeviceGuard guard(m->ctx[r]->device); if (r < m->b_shard.size()) m->b_shard[r].release(); if (r == 0) m->b_gather.release(); }
+        pc_ctx_destroy(m->ctx[r]);
+    }
+    delete m;
+}
+
+extern "C" int pc_multi_devices(const pc_multi* m) { return m ? (int)m->ctx.size() : -1; }
+
+// Every device gets the same packed genomes (they are replicated: 0.2 GB at N = 5,000), in parallel.  with_residues = 0: part 1 only
+// (all the set metrics need); an aai / peq fill uploads the residues on demand.
+extern "C" int pc_multi_upload(pc_multi* m, const pc_packed* g, int with_residues) {
+    if (!m || !g) { pc_set_error("pc_multi_upload: NULL argument"); return PC_ERR_ARG; }
+    m->uploaded = false; m->residues = false;
+    int rc = multi_each(m, [&](int r) { return with_residues ? pc_upload(m->ctx[r], g) : pc_upload_sets(m->ctx[r], g); });
+    if (rc != PC_OK) return rc;
+    m->uploaded = true; m->residues = with_residues != 0;
+    return PC_OK;
+}
+extern "C" int pc_multi_upload_residues(pc_multi* m, const pc_packed* g) {
+    if (!m || !g) { pc_set_error("pc_multi_upload_residues: NULL argument"); return PC_ERR_ARG; }
+    if (!m->uploaded) { pc_set_error("pc_multi_upload_residues: pc_multi_upload first"); return PC_ERR_STATE; }
+    int rc = multi_each(m, [&](int r) { return pc_upload_residues(m->ctx[r], g); });
+    if (rc == PC_OK) m->residues = true;
+    return rc;
+}
+extern "C" int pc_multi_set_tie_rule(pc_multi* m, int rule) {
+    if (!m) { pc_set_error("pc_multi_set_tie_rule: NULL"); return PC_ERR_ARG; }
+    for (pc_ctx* c : m->ctx) { const int rc = pc_set_tie_rule(c, rule); if (rc != PC_OK) return rc; }
+    return PC_OK;
+}
+
+// The whole matrix over the devices of `m`: *out_host points to f64[N(N-1)/2] in page-locked memory the ROOT context owns (valid until
+// the next fill or upload).  stats (optional, an array of pc_multi_devices() entries): every device's own fill.  exchange_ms /
+// assemble_ms (optional): HIP-event times of the slowest device's copy to the root and of the root's permutation.
+extern "C" int pc_multi_fill_borrow(pc_multi* m, int metric, int as_distance, const double** out_host, pc_stats* stats, float* exchange_ms, float* assemble_ms) {
+    if (!m || !out_host) { pc_set_error("pc_multi_fill_borrow: NULL argument"); return PC_ERR_ARG; }
+    *out_host = nullptr;
+    if (!m->uploaded) { pc_set_error("pc_multi_fill_borrow: pc_multi_upload first"); return PC_ERR_STATE; }
+    const int world = (int)m->ctx.size();
+    pc_ctx* root = m->ctx[0];
+    if (world == 1) {
+        if (exchange_ms) *exchange_ms = 0.f;
+        if (assemble_ms) *assemble_ms = 0.f;
+        return pc_fill_borrow(root, metric, as_distance, out_host, stats);
+    }
+    const int N = root->dev.N;
+    const int64_t np = (int64_t)N * (N - 1) / 2;
+    // 1 the deal (every context computes the same one), shard buffers
+    int rc = multi_each(m, [&](int r) -> int {
+        pc_ctx* c = m->ctx[r];
+        int e = pc_set_shard_balanced(c, r, world);
+        if (e != PC_OK) return e;
+        PcDeviceGuard guard(c->device);
+        return abi_rc(m->b_shard[r].ensure((size_t)std::max<int64_t>(c->shard_stride, 1) * 8));
+    });
+    if (rc != PC_OK) return rc;
+    const int64_t stride = root->shard_stride;
+    for (pc_ctx* c : m->ctx) if (c->shard_stride != stride) { pc_set_error("pc_multi_fill_borrow: the devices disagree on the deal (stride %lld vs %lld)", (long long)c->shard_stride, (long long)stride); return PC_ERR_STATE; }
+    {
+        PcDeviceGuard guard(root->device);
+        if ((rc = abi_rc(m->b_gather.ensure((size_t)std::max<int64_t>(stride, 1) * 8 * (size_t)world))) ||
+            (rc = abi_rc(root->b_out.ensure((size_t)std::max<int64_t>(np, 1) * 8)))) return rc;
+        const size_t bytes = (size_t)std::max<int64_t>(np, 1) * 8;
+        if (bytes > root->h_out_cap) {
+            if (root->h_out) { (void)hipHostFree(root->h_out); root->h_out = nullptr; root->h_out_cap = 0; }
+            const size_t want = bytes + bytes / 8;
+            hipError_t e = hipHostMalloc((void**)&root->h_out, want, hipHostMallocDefault);
+            if (e != hipSuccess) { pc_set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); root->h_out = nullptr; return PC_ERR_HIP; }
+            root->h_out_cap = want;
+        }
+    }
+    // 2 every device fills its shard, then copies it to its slice of the root's gather buffer: the one exchange
+    std::vector<float> xms((size_t)world, 0.f);
+    std::vector<pc_stats> local((size_t)world);
+    rc = multi_each(m, [&](int r) -> int {
+        pc_ctx* c = m->ctx[r];
+        int e = pc_fill_shard_dev(c, metric, as_distance, m->b_shard[r].p, c->stream, &local[r]);       // (with stats: returns when the fill is done)
+        if (e != PC_OK) return e;
+        PcDeviceGuard guard(c->device);
+        PC_HIP(hipEventRecord(c->ev[0], c->stream));
+        double* dst = m->b_gather.as<double>() + (size_t)r * (size_t)stride;
+        if (c->device == root->device) PC_HIP(hipMemcpyAsync(dst, m->b_shard[r].p, (size_t)stride * 8, hipMemcpyDeviceToDevice, c->stream));
+        else PC_HIP(hipMemcpyPeerAsync(dst, root->device, m->b_shard[r].p, c->device, (size_t)stride * 8, c->stream));
+        PC_HIP(hipEventRecord(c->ev[1], c->stream));
+        PC_HIP(hipStreamSynchronize(c->stream));
+        PC_HIP(hipEventElapsedTime(&xms[r], c->ev[0], c->ev[1]));
+        return (int)PC_OK;
+    });
+    if (rc != PC_OK) return rc;
+    // 3 the root permutes the shards into condensed order and delivers
+    {
+        PcDeviceGuard guard(root->device);
+        PC_HIP(hipEventRecord(root->ev[0], root->stream));
+        if ((rc = pc_assemble_dev(root, m->b_gather.p, world, root->b_out.p, root->stream))) return rc;
+        PC_HIP(hipEventRecord(root->ev[1], root->stream));
+        if (np) PC_HIP(hipMemcpyAsync(root->h_out, root->b_out.p, (size_t)np * 8, hipMemcpyDeviceToHost, root->stream));
+        PC_HIP(hipStreamSynchronize(root->stream));
+        if (assemble_ms) PC_HIP(hipEventElapsedTime(assemble_ms, root->ev[0], root->ev[1]));
+    }
+    if (exchange_ms) *exchange_ms = *std::max_element(xms.begin(), xms.end());
+    if (stats) for (int r = 0; r < world; ++r) stats[r] = local[r];
+    *out_host = root->h_out;
+    return PC_OK;
 }

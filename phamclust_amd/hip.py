@@ -48,7 +48,8 @@ EXPORTS = ["pc_version", "pc_test_hooks", "pc_last_error", "pc_ctx_create", "pc_
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs",
            "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev", "pc_upload_sets", "pc_upload_residues", "pc_set_plan_budget", "pc_chunk_plan",
-           "pc_variant_width", "pc_last_set_kernel"]
+           "pc_variant_width", "pc_last_set_kernel", "pc_multi_create", "pc_multi_destroy", "pc_multi_devices", "pc_multi_upload",
+           "pc_multi_upload_residues", "pc_multi_set_tie_rule", "pc_multi_fill_borrow"]
 NEEDS_RESIDUES = ("aai", "peq", "aai_ppos")
 
 _lib = None
@@ -111,6 +112,15 @@ def load():
     L.pc_shard_table.argtypes = [vp, _i32p, _i64p]
     L.pc_target_costs.argtypes = [vp, _u64p]
     L.pc_last_set_kernel.argtypes = [vp]
+    L.pc_multi_create.argtypes = [ctypes.POINTER(vp), _i32p, ctypes.c_int]
+    L.pc_multi_destroy.argtypes = [vp]
+    L.pc_multi_destroy.restype = None
+    L.pc_multi_devices.argtypes = [vp]
+    L.pc_multi_upload.argtypes = [vp, ctypes.POINTER(PcPacked), ctypes.c_int]
+    L.pc_multi_upload_residues.argtypes = [vp, ctypes.POINTER(PcPacked)]
+    L.pc_multi_set_tie_rule.argtypes = [vp, ctypes.c_int]
+    L.pc_multi_fill_borrow.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_f64p), ctypes.POINTER(PcStats),
+                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.pc_set_tie_rule.argtypes = [vp, ctypes.c_int]
     L.pc_get_tie_rule.argtypes = [vp]
     _lib = L
@@ -424,3 +434,89 @@ class Context:
         out = np.empty_like(v)
         self._check(self._lib.pc_round6_probe(self._h, _ptr(v, _f64p), _ptr(out, _f64p), v.shape[0]))
         return out
+
+
+class MultiContext:
+    """Several GPUs of this node driven from THIS process (``pc_multi_*``: a context and a host thread per device inside the
+    library, the shard exchange as device-to-device copies) -- the multi-GPU route that costs no launcher, no interpreter and no
+    process group per GPU.  ``device_ids[0]`` delivers the matrix; an id may repeat (several contexts on one GPU: rehearsal).
+    Same surface as :class:`Context` where it matters to ``matrix_de_novo``: ``upload`` / ``fill``."""
+
+    def __init__(self, device_ids):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        self._packed = None
+        self.device_ids = [int(x) for x in device_ids]
+        ids = np.ascontiguousarray(self.device_ids, dtype=np.int32)
+        rc = self._lib.pc_multi_create(ctypes.byref(self._h), _ptr(ids, _i32p), int(ids.shape[0]))
+        if rc != 0:
+            raise HipLibraryError(f"libphamclust_hip: status {rc}: {self._lib.pc_last_error().decode()}")
+
+    _check = Context._check
+    _struct = staticmethod(Context._struct)
+    _invalidate_loans = Context._invalidate_loans
+
+    @property
+    def n_devices(self):
+        return len(self.device_ids)
+
+    @property
+    def n_pairs(self):
+        return self._packed.n_pairs
+
+    def close(self):
+        self._invalidate_loans()
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pc_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                          # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def upload(self, packed, residues=True):
+        packed.validate()
+        s = self._struct(packed)
+        self._invalidate_loans()
+        self._check(self._lib.pc_multi_upload(self._h, ctypes.byref(s), int(bool(residues))))
+        self._packed, self._residues = packed, bool(residues)
+        return self
+
+    def set_tie_rule(self, rule):
+        self._check(self._lib.pc_multi_set_tie_rule(self._h, int(rule)))
+
+    def fill(self, metric, as_distance=True, want_stats=False, borrow=True):
+        """The whole matrix over all devices: condensed f64 vector (a loan of the root context's pinned memory, like
+        ``Context.fill(borrow=True)``; ``borrow=False`` copies it).  Stats: the root device's fill plus ``per_device`` (every
+        device's own), ``ms_exchange`` (slowest device-to-root copy), ``ms_assemble``."""
+        if self._packed is None:
+            raise HipLibraryError("no genomes uploaded")
+        if metric in NEEDS_RESIDUES and not self._residues:
+            s = self._struct(self._packed)
+            self._check(self._lib.pc_multi_upload_residues(self._h, ctypes.byref(s)))
+            self._residues = True
+        self._invalidate_loans()
+        stats = (PcStats * self.n_devices)()
+        ptr, x_ms, a_ms = _f64p(), ctypes.c_float(0.0), ctypes.c_float(0.0)
+        self._check(self._lib.pc_multi_fill_borrow(self._h, METRIC_IDS[metric], int(bool(as_distance)), ctypes.byref(ptr), stats,
+                                                   ctypes.byref(x_ms), ctypes.byref(a_ms)))
+        view = np.ctypeslib.as_array(ptr, shape=(max(self.n_pairs, 1),))[:self.n_pairs]
+        view.flags.writeable = False
+        out = BorrowedArray(view, self)
+        self._loans.append(weakref.ref(out))
+        if not borrow:
+            out = out.copy()
+        if not want_stats:
+            return out
+        per = [s.as_dict() for s in stats]
+        merged = dict(per[0], per_device=per, ms_exchange=float(x_ms.value), ms_assemble=float(a_ms.value), n_devices=self.n_devices,
+                      ms_total=max(p["ms_total"] for p in per))
+        return out, merged

@@ -322,6 +322,27 @@ def get_context(device_id=None):
     return _CONTEXTS[device_id]
 
 
+def in_process_devices():
+    """Device ordinals of an in-process multi-GPU fill, or None: ``PHAMCLUST_GPUS=N`` (what ``phamclust --gpus N`` sets when it
+    keeps the job in this process) -> devices 0..N-1; ``PHAMCLUST_GPU_IDS=0,0,1`` names them (an id may repeat: rehearsal on a box
+    with fewer GPUs).  Ignored under a launcher (WORLD_SIZE > 1: one process per GPU is then the job's shape)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return None
+    ids = os.environ.get("PHAMCLUST_GPU_IDS")
+    if ids:
+        return [int(x) for x in ids.split(",")]
+    n = int(os.environ.get("PHAMCLUST_GPUS", "1"))
+    return list(range(n)) if n > 1 else None
+
+
+def get_multi_context(device_ids):
+    from phamclust_amd import hip
+    key = ("multi",) + tuple(device_ids)
+    if key not in _CONTEXTS:
+        _CONTEXTS[key] = hip.MultiContext(device_ids)
+    return _CONTEXTS[key]
+
+
 def _metric_name(func):
     from phamclust_amd import metrics
     return metrics.ACCELERATED.get(func)
@@ -344,7 +365,9 @@ def matrix_de_novo(genomes, func, cpus, as_distance=True):
     (matrix.py:471-472), this spreads them over the GPUs of the job it runs in: under
     ``python -m torch.distributed.run --nproc-per-node N`` (one process per GPU; ``phamclust --gpus N`` starts that
     for you) every rank calls this with the same genomes, fills its static shard of the pair list, and ONE gather
-    brings the shards to rank 0.  Rank 0 returns the matrix; every other rank returns ``None``.  For those six, ``cpus`` is
+    brings the shards to rank 0.  Rank 0 returns the matrix; every other rank returns ``None``.  Without a launcher,
+    ``PHAMCLUST_GPUS=N`` (set by ``phamclust --gpus N``) spreads the same shards over N GPUs from THIS process (``pc_multi_*``:
+    a host thread per device inside the library, device-to-device copies for the exchange).  For those six, ``cpus`` is
     accepted for signature compatibility only; any OTHER callable is filled the reference's way -- per pair, in its batch
     order, over ``cpus`` joblib workers (in this process when ``cpus`` is 1).
     """
@@ -359,17 +382,18 @@ def matrix_de_novo(genomes, func, cpus, as_distance=True):
         t0 = time.perf_counter()
         packed = _packed_of(genomes)
         t1 = time.perf_counter()
-        ctx = get_context()
+        devices = in_process_devices()
+        ctx = get_multi_context(devices) if devices else get_context()
         # gcs / jc / pocp / af never read a residue (metrics.py:26-157): their upload skips the residue stage
         ctx.upload(packed, residues=metric in ("aai", "peq"))
         t2 = time.perf_counter()
         if world > 1:
             condensed, stats = distributed.fill_condensed(ctx, metric, as_distance)
-        else:
+        else:                                              # one process: one GPU, or several through pc_multi_* (no launcher, no process group)
             condensed, stats = ctx.fill(metric, as_distance=as_distance, want_stats=True, borrow=True)
         t3 = time.perf_counter()
         LAST_FILL.clear()
-        LAST_FILL.update(stats, metric=metric, n_genomes=len(genomes), genome_pairs=packed.n_pairs, n_gpus=world, rank=rank,
+        LAST_FILL.update(stats, metric=metric, n_genomes=len(genomes), genome_pairs=packed.n_pairs, n_gpus=len(devices) if devices else world, rank=rank,
                          pack_s=t1 - t0, upload_s=t2 - t1, fill_s=t3 - t2)
         logging.debug(f"{len(genomes)} genomes -> {packed.n_pairs} edges on {world} device(s): pack {t1 - t0:.3f} s, "
                       f"upload {t2 - t1:.3f} s, fill+gather+D2H {t3 - t2:.3f} s (kernels {stats['ms_total']:.3f} ms on this rank)")

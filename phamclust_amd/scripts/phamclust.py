@@ -318,23 +318,29 @@ def main(argv=None):
     rank, _, world = distributed.env_world()
     gpus_note = None
     if args.gpus > 1 and world == 1:
-        # `--gpus N`: N ranks cost seconds to start (an interpreter, a torch import and a process-group init each); the
-        # reference clamps its workers to the work too (matrix.py:460-462).  Load the genomes here -- host code only, no GPU
-        # call -- estimate the fill, and start the ranks only when they can win that back.
-        n_ranks = args.gpus
+        # `--gpus N`.  Two routes (startup.multi_gpu_route): by default THIS process drives the N GPUs (pc_multi_*: nothing to
+        # launch); PHAMCLUST_MULTI=launcher re-runs the command as N ranks under torch.distributed.run, which costs seconds
+        # before the first pair (an interpreter, a torch import and a process group per rank).  Either way the reference's rule
+        # applies -- never more workers than work (matrix.py:460-462): load the genomes (host code only, no GPU call), estimate
+        # the fill, and spread it only when N GPUs can win their start-up back.
+        route = startup.multi_gpu_route()
+        n_gpus = args.gpus
         if not args.genome_dir:
             genomes = load_genomes(args.infile)
             TIMELINE.mark("load_genomes_for_estimate")
             packed = packed_behind(genomes)
             if packed is not None:
-                n_ranks, gpus_note = startup.choose_gpus(args.gpus, packed, args.metric)
+                n_gpus, gpus_note = startup.choose_gpus(args.gpus, packed, args.metric, route)
                 _PRELOADED[str(args.infile)] = genomes
-        if n_ranks > 1:
-            # re-run this command line as N ranks, one per GPU, under the launcher -- as a child process, before this
-            # process has made a single GPU call
+        if n_gpus > 1 and route == "launcher":
+            # as N ranks, one per GPU -- as a child process, before this process has made a single GPU call
             passed = list(sys.argv[1:] if argv is None else argv)
-            sys.exit(distributed.launch_ranks(n_ranks, "phamclust_amd", [str(x) for x in passed],
+            sys.exit(distributed.launch_ranks(n_gpus, "phamclust_amd", [str(x) for x in passed],
                                               env={"PHAMCLUST_T0": repr(TIMELINE.t_launch), "PHAMCLUST_FORCE_GPUS": "1"}))
+        if n_gpus > 1:
+            os.environ["PHAMCLUST_GPUS"] = str(n_gpus)             # matrix_de_novo: devices 0..N-1 from this process (PHAMCLUST_GPU_IDS names others)
+        else:
+            os.environ.pop("PHAMCLUST_GPUS", None); os.environ.pop("PHAMCLUST_GPU_IDS", None)
     if world == 1:
         os.environ.setdefault("PHAMCLUST_NO_TORCH", "1")           # one rank: nothing needs torch (hip.load() then skips its import)
     if args.device is not None and world == 1:

@@ -3,9 +3,11 @@
 The reference pays its worker-pool start-up inside ``matrix_de_novo`` (matrix.py:471-472) and clamps the workers to the work
 (matrix.py:460-462: never more CPUs than genome pairs).  Here ``--gpus N`` means one process per GPU under
 ``torch.distributed.run``: one interpreter, one torch import and one RCCL initialisation PER RANK before any rank fills a pair --
-seconds, against a fill that takes 0.6 s for 5,000 genomes on one GPU.  So the CLI estimates the fill from the loaded genomes
-before it touches a GPU, compares what N ranks would save with what starting them costs (measured:
-``profiles/r04/launch_cost.txt``), and stays on one GPU when the job loses; the log says why.
+seconds, against a fill that takes 0.6 s for 5,000 genomes on one GPU.  So ``--gpus N`` by default keeps the job in ONE process
+(``pc_multi_*``: the library drives a context per device; 0.1-0.2 s of start-up), the launcher route is opt-in
+(``PHAMCLUST_MULTI=launcher``), and either way the CLI estimates the fill from the loaded genomes before it touches a GPU, compares
+what N GPUs would save with what starting them costs (measured: ``profiles/r04/final/launch_cost.txt``), and stays on one GPU when
+the job loses; the log says why.
 """
 
 import json
@@ -15,9 +17,9 @@ import time
 import numpy as np
 
 # Measured on the one-GPU box with the launcher and the gloo rehearsal transport (tools/launch_cost.py ->
-# profiles/r04/launch_cost.txt, synth(5000,5000) -m peq): command start -> matrix on the host 2.73 s on one rank, 5.23 s as 2 ranks,
-# 5.34 s as 4 -- the parent's own start, its load for this estimate and the launcher 1.7 s, the ranks' torch import and process
-# group ~1.05 s -- i.e. ~2.5 s of fixed cost, while the fill stage itself was no faster (the ranks shared one GPU there).  RCCL's
+# profiles/r04/final/launch_cost.txt, synth(5000,5000) -m peq): command start -> matrix on the host 2.0-2.7 s on one rank, 4.5-5.2 s as
+# 2 ranks, 4.7-5.3 s as 4 -- the parent's own start, its load for this estimate and the launcher 1.7 s, the ranks' torch import and
+# process group ~1.05 s -- i.e. 2.4-2.6 s of fixed cost, while the fill stage itself was no faster (the ranks shared one GPU there).  RCCL's
 # communicator set-up, which gloo does not pay, is allowed one more second.  PHAMCLUST_LAUNCH_COST_S overrides.
 LAUNCH_COST_S = 3.5
 # one GPU, sustained (bench.py / profiles/): DP cells per second of the alignment kernels, genome pairs per second of the
@@ -59,12 +61,28 @@ class Timeline:
         return "timing: " + json.dumps(self.as_dict())
 
 
-def launch_cost_seconds(n_gpus):
-    """Fixed cost of running as ``n_gpus`` ranks instead of in this process."""
+# ... and of the in-process route (pc_multi_*: a context, an upload and a host thread per extra device, all in parallel; no
+# launcher, no second interpreter, no process group).  Measured the same way (profiles/r04/final/launch_cost.txt; the "devices"
+# were contexts on ONE GPU, so their uploads took turns): 0.08 s for 2 devices, 0.23 s for 4.
+INPROCESS_COST_S = 0.25
+
+
+def multi_gpu_route():
+    """How ``phamclust --gpus N`` spreads the fill: "process" (default: this process drives all N GPUs through ``pc_multi_*``) or
+    "launcher" (``PHAMCLUST_MULTI=launcher``: N ranks under torch.distributed.run, one RCCL gather -- the route ``bench.py``'s
+    N > 1 contract measures)."""
+    route = os.environ.get("PHAMCLUST_MULTI", "process")
+    if route not in ("process", "launcher"):
+        raise ValueError(f"PHAMCLUST_MULTI={route!r}: expected 'process' or 'launcher'")
+    return route
+
+
+def launch_cost_seconds(n_gpus, route="launcher"):
+    """Fixed cost of spreading a fill over ``n_gpus`` devices instead of one."""
     if n_gpus <= 1:
         return 0.0
     env = os.environ.get("PHAMCLUST_LAUNCH_COST_S")
-    return float(env) if env else LAUNCH_COST_S
+    return float(env) if env else (LAUNCH_COST_S if route == "launcher" else INPROCESS_COST_S)
 
 
 def alignment_cells(packed):
@@ -90,9 +108,9 @@ def estimate_fill_seconds(packed, metric):
     return seconds
 
 
-def choose_gpus(requested, packed, metric):
-    """How many ranks to start for ``--gpus requested``: (n, reason).  N ranks split the fill N ways at best and cost
-    launch_cost_seconds(N) before they start; when that is more than they save, one GPU is faster."""
+def choose_gpus(requested, packed, metric, route="launcher"):
+    """How many GPUs to use for ``--gpus requested``: (n, reason).  N devices split the fill N ways at best and cost
+    launch_cost_seconds(N, route) before they start; when that is more than they save, one GPU is faster."""
     requested = max(1, int(requested))
     if requested == 1:
         return 1, "one GPU requested"
@@ -100,8 +118,9 @@ def choose_gpus(requested, packed, metric):
         return requested, "PHAMCLUST_FORCE_GPUS is set: no estimate"
     one = estimate_fill_seconds(packed, metric)
     saved = one * (1.0 - 1.0 / requested)
-    cost = launch_cost_seconds(requested)
+    cost = launch_cost_seconds(requested, route)
+    what = "interpreters, torch, process group" if route == "launcher" else "a context and an upload per device"
     if saved <= cost:
-        return 1, (f"estimated {metric} fill of {packed.n_genomes} genomes on one GPU: {one:.2f} s; {requested} ranks would save at most "
-                   f"{saved:.2f} s and cost ~{cost:.1f} s to start (interpreters, torch, process group): running on ONE GPU")
-    return requested, (f"estimated {metric} fill on one GPU: {one:.2f} s; {requested} ranks save up to {saved:.2f} s for ~{cost:.1f} s of start-up")
+        return 1, (f"estimated {metric} fill of {packed.n_genomes} genomes on one GPU: {one:.2f} s; {requested} GPUs would save at most "
+                   f"{saved:.2f} s and cost ~{cost:.2f} s to start ({what}): running on ONE GPU")
+    return requested, (f"estimated {metric} fill on one GPU: {one:.2f} s; {requested} GPUs save up to {saved:.2f} s for ~{cost:.2f} s of start-up ({what})")

@@ -1566,3 +1566,32 @@ with hip.Context(0) as ctx:
         assert run.returncode == 0, (name, run.stdout[-1500:], run.stderr[-3000:])
         seen[name] = json.loads(run.stdout.strip().splitlines()[-1])
     assert seen["default"]["tasks"] == seen["per_class"]["tasks"] and seen["default"]["launches"] < seen["per_class"]["launches"], seen
+
+
+def test_multi_context_one_process_many_devices(native_built):
+    """pc_multi_* (pc_ctx_create(out, device_ids, n_dev)): one process, a context and a host thread per device, the
+    cost-balanced deal of the target genomes, ONE exchange (each device copies its shard to the root, device to device), device-side
+    assembly.  Rehearsed with 1-4 contexts on this box's one GPU: every metric equals the single-context fill bit for bit (which
+    the other tests hold to the oracle), the devices' shards partition the pairs, uneven genomes included."""
+    from phamclust_amd import hip
+    from phamclust_amd.synth import synth_packed, synth_real
+    O = _oracle()
+    for packed in (synth_packed(211, 700, seed=31), synth_real(150, seed=4)):
+        with hip.Context(0) as one:
+            one.upload(packed)
+            want = {m: np.asarray(one.fill(m)).copy() for m in ALL_METRICS + ["aai_ppos"]}
+        assert np.array_equal(want["peq"], O.fill(packed, "peq"))
+        for ids in ([0], [0, 0], [0, 0, 0, 0]):
+            with hip.MultiContext(ids) as multi:
+                multi.upload(packed, residues=False)                  # the residues follow on demand, on every device
+                for m in ALL_METRICS + ["aai_ppos"]:
+                    got, st = multi.fill(m, want_stats=True)
+                    assert np.array_equal(got, want[m]), (ids, m)
+                    assert st["n_devices"] == len(ids) and len(st["per_device"]) == len(ids)
+                    assert sum(p["n_pairs"] for p in st["per_device"]) == packed.n_pairs
+                    if len(ids) > 1 and m == "peq":
+                        cells = [p["n_cells"] for p in st["per_device"]]
+                        assert max(cells) <= 1.2 * (sum(cells) / len(cells)) + 1e6          # the deal balances the alignment work
+                assert np.array_equal(multi.fill("jc", as_distance=False), O.fill(packed, "jc", as_distance=False))
+    with pytest.raises(hip.HipLibraryError):
+        hip.MultiContext([0, 99])

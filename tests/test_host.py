@@ -436,7 +436,7 @@ def test_gpus_request_is_clamped_to_the_work(native_built, tmp_path, monkeypatch
     _, n_aln, n_cells = O.fill_rows(small, "peq", 0, small.n_genomes)
     assert n_cells <= cells <= 1.2 * n_cells                       # an upper estimate, close (paralog-vs-paralog repeats only)
     n, why = startup.choose_gpus(8, small, "peq")
-    assert n == 1 and "running on ONE GPU" in why and "8 ranks" in why
+    assert n == 1 and "running on ONE GPU" in why and "8 GPUs" in why and "process group" in why
     assert startup.choose_gpus(1, small, "peq")[0] == 1
     assert startup.choose_gpus(4, small, "jc")[0] == 1             # set metrics: microseconds of kernel, never worth a launch
     monkeypatch.setenv("PHAMCLUST_LAUNCH_COST_S", "0.000001")
@@ -451,6 +451,15 @@ def test_gpus_request_is_clamped_to_the_work(native_built, tmp_path, monkeypatch
     big = copy.copy(small)
     big.seq_off = small.seq_off * 40
     assert startup.estimate_fill_seconds(big, "peq") > 1600 * 0.9 * startup.estimate_fill_seconds(small, "peq") - 1.0
+    # the in-process route (pc_multi_*) has almost nothing to start: the same request goes through once the fill is worth 0.35 s
+    assert startup.multi_gpu_route() == "process"
+    monkeypatch.setenv("PHAMCLUST_MULTI", "launcher")
+    assert startup.multi_gpu_route() == "launcher"
+    monkeypatch.delenv("PHAMCLUST_MULTI")
+    assert startup.launch_cost_seconds(8, "process") < 0.1 * startup.launch_cost_seconds(8, "launcher") + 0.1
+    n, why = startup.choose_gpus(8, small, "peq", route="process")
+    assert n == 1 and "a context and an upload per device" in why          # 120 genomes: milliseconds of fill
+    assert startup.choose_gpus(8, big, "peq", route="process")[0] == 8
     line = startup.Timeline()
     line.mark("imports")
     assert line.line().startswith("timing: {") and "imports" in line.as_dict()

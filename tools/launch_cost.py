@@ -24,11 +24,15 @@ lines = [f"# tools/launch_cost.py -n {a.n} --ranks {a.ranks} -m {a.metric}: wall
          "# interpreter_start = command start -> rank 0's interpreter running (under --gpus N: the parent's own start, its load for the estimate,",
          "#   torch.distributed.run); imports = the package and its dependencies; process_group_and_context = torch import + init_process_group + HIP context"]
 rows = {}
-for ranks in [int(x) for x in a.ranks.split(",")]:
+runs = [(1, "process")] + [(r, route) for r in [int(x) for x in a.ranks.split(",")] if r > 1 for route in ("process", "launcher")]
+for ranks, route in runs:
     best = None
     for rep in range(2):
-        out = os.path.join(work, f"out_{ranks}_{rep}")
-        env = dict(os.environ, PYTHONPATH=REPO, PHAMCLUST_DIST_BACKEND="gloo", PHAMCLUST_FORCE_GPUS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = os.path.join(work, f"out_{ranks}_{route}_{rep}")
+        # "process": THIS process drives `ranks` contexts (all on device 0 here) through pc_multi_*; "launcher": `ranks` processes under
+        # torch.distributed.run sharing the GPU, the gather over gloo
+        env = dict(os.environ, PYTHONPATH=REPO, PHAMCLUST_DIST_BACKEND="gloo", PHAMCLUST_FORCE_GPUS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PHAMCLUST_MULTI=route, PHAMCLUST_GPU_IDS=",".join(["0"] * ranks))
         t0 = time.time()
         proc = subprocess.run([sys.executable, "-m", "phamclust_amd", tsv, out, "-m", a.metric, "--gpus", str(ranks)], env=env, capture_output=True, text=True)
         wall = time.time() - t0
@@ -40,19 +44,18 @@ for ranks in [int(x) for x in a.ranks.split(",")]:
         timing["fill_line"] = [l.split("INFO: ", 1)[-1] for l in log.splitlines() if "genome-pairs/s" in l][-1]
         shutil.rmtree(out, ignore_errors=True)
         best = timing
-    rows[ranks] = best
-    lines.append(f"--gpus {ranks}: " + json.dumps(best))
+    rows[(ranks, route)] = best
+    lines.append(f"--gpus {ranks} ({route}): " + json.dumps(best))
     print(lines[-1], flush=True)
-if 1 in rows:
-    keys = ("interpreter_start", "imports", "load_genomes_for_estimate", "torch_import_and_process_group", "load_genomes", "pack", "process_group_and_context", "upload", "fill_exchange_d2h")
-    base = sum(rows[1].get(k, 0.0) for k in keys)
-    for ranks, t in rows.items():
-        if ranks > 1:
-            upto = sum(t.get(k, 0.0) for k in keys)
-            lines.append(f"# --gpus {ranks} against --gpus 1, command start -> matrix on the host: {upto:.2f} s against {base:.2f} s; fill stage alone "
-                         f"{t.get('fill_exchange_d2h', 0.0):.3f} s against {rows[1].get('fill_exchange_d2h', 0.0):.3f} s -> fixed cost of the launch ~ "
-                         f"{upto - t.get('fill_exchange_d2h', 0.0) - (base - rows[1].get('fill_exchange_d2h', 0.0)):.2f} s")
-            print(lines[-1])
+keys = ("interpreter_start", "imports", "load_genomes_for_estimate", "torch_import_and_process_group", "load_genomes", "pack", "process_group_and_context", "upload", "fill_exchange_d2h")
+base = sum(rows[(1, "process")].get(k, 0.0) for k in keys)
+for (ranks, route), t in rows.items():
+    if ranks > 1:
+        upto = sum(t.get(k, 0.0) for k in keys)
+        lines.append(f"# --gpus {ranks} ({route}) against --gpus 1, command start -> matrix on the host: {upto:.2f} s against {base:.2f} s; fill stage alone "
+                     f"{t.get('fill_exchange_d2h', 0.0):.3f} s against {rows[(1, 'process')].get('fill_exchange_d2h', 0.0):.3f} s (the devices are ONE GPU here) -> fixed cost ~ "
+                     f"{upto - t.get('fill_exchange_d2h', 0.0) - (base - rows[(1, 'process')].get('fill_exchange_d2h', 0.0)):.2f} s")
+        print(lines[-1])
 if a.out:
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     open(a.out, "w").write("\n".join(lines) + "\n")
