@@ -339,7 +339,11 @@ def get_multi_context(device_ids):
     from phamclust_amd import hip
     key = ("multi",) + tuple(device_ids)
     if key not in _CONTEXTS:
-        _CONTEXTS[key] = hip.MultiContext(device_ids)
+        try:
+            _CONTEXTS[key] = hip.MultiContext(device_ids)
+        except hip.HipLibraryError as exc:
+            raise hip.HipLibraryError(f"{exc} -- asked for devices {list(device_ids)} (--gpus / PHAMCLUST_GPUS / PHAMCLUST_GPU_IDS): "
+                                      f"ask for the GPUs this node has, or name them with PHAMCLUST_GPU_IDS") from None
     return _CONTEXTS[key]
 
 
