@@ -277,10 +277,14 @@ int pc_round6_probe(pc_ctx* ctx, const double* in, double* out, int64_t n);
  *     PC_FUSE=0                 one launch per launch class instead of one per register tier
  *     PC_STRIP=0                column genes beyond 4,096 residues on the one-lane-per-alignment kernel instead of strip-mined passes
  *     PC_ALIGN_ORDER=size       largest class first instead of longest column genes first
+ *     PC_STRIP_STREAMS=0        strip-mined launches one after the other on the caller's stream, sharing one scratch region (default: a region and a stream each)
+ *     PC_SLAB_BUDGET=n          bytes the strip-mined launches' own scratch regions may take together (3 GB); what does not fit shares the first region, in line
+ *     PC_LONG_PRIORITY=0        the strip-mined launches' streams at ordinary priority (default: the highest the device offers)
  *   read per fill / per launch (the tests switch them between calls)
  *     PC_POPC_TILE=32|64        force the word-split 32 x 32 / the 64 x 64 popcount tile kernel
  *     PC_SET_KERNEL=popc|sparse|sparse64|walker    force a kernel family for gcs / jc / pocp / af where it exists for the metric
  *     PC_S64_CHUNKS=n           at least n mask chunks in the 64 x 64 sparse tile kernel
+ *     PC_PIPE=0|n               strip-mined launches: never pipelined (one row per wave) / always, the passes of a row over n <= 8 waves (default: by the launch's size)
  *   only in libphamclust_hip_hooks.so (compiled with -DPC_TEST_HOOKS; pc_test_hooks() == 1)
  *     PC_FAKE_OOM_ABOVE=n       device allocations above n bytes made while a fill is planning fail (fault injection)
  * The Python package adds PHAMCLUST_DEVICE, PHAMCLUST_DIST_BACKEND, PHAMCLUST_DIST_MODE, PHAMCLUST_DIST_TIMEOUT_S, PHAMCLUST_LAUNCH_COST_S,

@@ -187,6 +187,14 @@ struct pc_ctx {
     hipStream_t aux[kAux] = {};             // alignment launches of different classes overlap on these
     hipEvent_t aux_ev[kAux + 1] = {};
     int n_streams = 8;                      // streams actually used (tuning knob: env PC_ALIGN_STREAMS at ctx creation)
+    // Streams for the few launches whose TASKS run for tens of milliseconds (strip-mined passes over long genes).  Their own, so
+    // that no other launch queues up behind them -- the runtime lays streams over a handful of hardware queues, and a queue runs
+    // its launches one after the other: behind a 30-ms strip launch sat a dozen launches of a millisecond each -- and of HIGH
+    // priority: those streams get hardware queues of their own, and their waves go first where they compete (they are the
+    // fill's critical path).  PC_LONG_PRIORITY=0: ordinary priority.
+    static constexpr int kLong = 4;
+    hipStream_t lng[kLong] = {};
+    hipEvent_t lng_ev[kLong] = {};
     int tie_rule = 0;                       // row of the aligner's tie-rule table (pc_set_tie_rule)
     int64_t lut_key = -1; const double* lut_ptr = nullptr;   // what the gcs / jc epilogue table in b_lut was built for
     hipEvent_t ev_last = nullptr;           // recorded at the end of every entry point that leaves work on a caller's stream
@@ -253,6 +261,16 @@ extern "C" int pc_ctx_create(pc_ctx** out, int device_id) {
     for (int i = 0; i < pc_ctx::kAux && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
     for (int i = 0; i <= pc_ctx::kAux && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming);
     if (const char* env = getenv("PC_ALIGN_STREAMS")) { int v = atoi(env); if (v >= 1 && v <= pc_ctx::kAux + 1) c->n_streams = v; }
+    {
+        int least = 0, greatest = 0;
+        const char* env = getenv("PC_LONG_PRIORITY");
+        const bool high = !(env && !strcmp(env, "0")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
+        for (int i = 0; i < pc_ctx::kLong && e == hipSuccess; ++i) {
+            if (high && hipStreamCreateWithPriority(&c->lng[i], hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); c->lng[i] = nullptr; }
+            if (!c->lng[i]) e = hipStreamCreateWithFlags(&c->lng[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lng_ev[i], hipEventDisableTiming);
+        }
+    }
     c->tie_rule = PC_TIE_RULE_DEFAULT;
     if (const char* env = getenv("PC_TIE_RULE")) { int v = atoi(env); if (v >= 0 && v < PC_NUM_TIE_RULES) c->tie_rule = v; }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_plan, 4096, hipHostMallocDefault);
@@ -279,6 +297,10 @@ extern "C" void pc_ctx_destroy(pc_ctx* c) {
     if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     for (int i = 0; i < pc_ctx::kAux; ++i) if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
     for (int i = 0; i <= pc_ctx::kAux; ++i) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
+    for (int i = 0; i < pc_ctx::kLong; ++i) {
+        if (c->lng[i]) { (void)hipStreamSynchronize(c->lng[i]); (void)hipStreamDestroy(c->lng[i]); }
+        if (c->lng_ev[i]) (void)hipEventDestroy(c->lng_ev[i]);
+    }
     if (c->h_plan) (void)hipHostFree(c->h_plan);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -999,17 +1021,37 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         if (x.max_lb != y.max_lb) return x.max_lb > y.max_lb;
         return x.base != y.base ? x.base < y.base : x.mode < y.mode;
     });
-    // scratch of the general kernel: sized once for the longest column gene that will use it (never re-allocated
-    // between launches)
-    size_t sbytes = 0;
+    // Scratch slab (sized before anything is launched, never re-allocated between launches).  The general kernel's launches share
+    // its first region and stay in order on the caller's stream.  Every strip-mined launch gets a region of its OWN behind it and one
+    // of the context's long-task streams (pc_ctx::lng): a collection's long-gene launches are few tasks of tens of milliseconds each -- a 6,600 x 6,600
+    // alignment on one wave takes 47 ms -- and lined up on one stream they were the critical path of the fill (synth_real(5000):
+    // three strip launches, 112 + 41 + 48 ms end to end, the last two on a nearly empty chip, under a fill of 243 ms).  Only
+    // what does not fit PC_SLAB_BUDGET (3 GB) shares the first region, in order, as before.
     // percent-positives: systolic where the profile cell can run (it reads "positive" from a table), general kernel elsewhere
     auto launch_variant = [&](const Launch& l) { const int v = pc_class_variant(l.base); return (ppos && !pc_nw_ppos_systolic(v, l.max_lb)) ? pc_nw_ppos_variant(l.max_lb) : v; };
     auto uses_slab = [&](const Launch& l) { const int v = launch_variant(l); return v < 0 || pc_launch_is_strip(v, l.max_lb, l.mode, ppos); };
-    for (const Launch& l : launches) {
+    struct Region { size_t off, bytes; bool own; };
+    std::vector<Region> region(launches.size(), Region{0, 0, false});
+    static const size_t slab_budget = [] { const char* e = getenv("PC_SLAB_BUDGET"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)3 << 30; }();
+    static const bool strips_in_line = getenv("PC_STRIP_STREAMS") && !strcmp(getenv("PC_STRIP_STREAMS"), "0");     // A/B: the r04 order
+    size_t shared = 0, sbytes = 0;
+    for (const Launch& l : launches) if (launch_variant(l) < 0) shared = std::max(shared, pc_nw_fallback_scratch_bytes(l.max_lb));
+    auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t own_total = 0;
+    for (size_t i = 0; i < launches.size(); ++i) {
+        const Launch& l = launches[i];
         const int v = launch_variant(l);
-        if (v < 0) sbytes = std::max(sbytes, pc_nw_fallback_scratch_bytes(l.max_lb));
-        else if (pc_launch_is_strip(v, l.max_lb, l.mode, ppos)) sbytes = std::max(sbytes, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
+        if (v < 0 || !pc_launch_is_strip(v, l.max_lb, l.mode, ppos)) continue;
+        const size_t need = up256(pc_nw_strip_launch_bytes(l.mode, (int)(l.end - l.begin), c->max_gene_len, c->n_cu, ppos));
+        if (!strips_in_line && c->n_streams > 1 && own_total + need <= slab_budget) { region[i] = Region{own_total, need, true}; own_total += need; }
+        else shared = std::max(shared, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
     }
+    shared = up256(shared);
+    for (size_t i = 0; i < launches.size(); ++i) {
+        if (region[i].own) region[i].off += shared;
+        else if (uses_slab(launches[i])) region[i] = Region{0, shared, false};
+    }
+    sbytes = shared + own_total;
     if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     // Launch classes of one register tier, cell and workgroup size share ONE launch (k_nw_systolic_tier, pc_nw_fuse_key): the
     // hardware queues run launches back to back, each waiting for the last workgroup of the one before it, and a fill's ~80
@@ -1027,9 +1069,13 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     }
     constexpr int kAux = pc_ctx::kAux;
     const int n_aux = std::min((int)groups.size(), c->n_streams) - 1;        // auxiliary streams this fill uses
+    int n_long = 0;                                                          // launches with a scratch region of their own: on the long-task streams
+    for (const Region& rg : region) if (rg.own) ++n_long;
+    n_long = std::min(n_long, (int)pc_ctx::kLong);
     PC_HIP(hipEventRecord(c->aux_ev[kAux], st));
     for (int k = 0; k < n_aux; ++k) PC_HIP(hipStreamWaitEvent(c->aux[k], c->aux_ev[kAux], 0));
-    int slot = 0, first_error = PC_OK;
+    for (int k = 0; k < n_long; ++k) PC_HIP(hipStreamWaitEvent(c->lng[k], c->aux_ev[kAux], 0));
+    int slot = 0, long_slot = 0, first_error = PC_OK;
     for (const Group& grp : groups) {
         int rc = PC_OK;
         if (grp.key >= 0) {
@@ -1046,22 +1092,27 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
             const Launch& l = launches[grp.members[0]];
             const int nt = (int)(l.end - l.begin);
             const int variant = launch_variant(l);
-            // launches that use the one scratch slab stay in order on the caller's stream
-            const bool slab = uses_slab(l);
-            hipStream_t ls = (slab || slot == 0) ? st : c->aux[slot - 1];
+            // launches that share the slab's first region stay in order on the caller's stream
+            const Region& rg = region[grp.members[0]];
+            const bool slab = rg.bytes != 0;
+            hipStream_t ls = rg.own ? c->lng[long_slot++ % n_long] : ((slab || slot == 0) ? st : c->aux[slot - 1]);
             rc = pc_launch_nw(variant, c->dev, task_list + l.begin, nt, c->b_bucket_row.as<int32_t>(),
-                              nullptr, res, slab ? c->b_scratch.p : nullptr,
-                              slab ? c->b_scratch.cap : 0, l.max_lb, ppos, c->tie_rule, pc_class_compare_only(l.base), ls, l.mode, c->max_gene_len);
+                              nullptr, res, slab ? (void*)((char*)c->b_scratch.p + rg.off) : nullptr,
+                              slab ? rg.bytes : 0, l.max_lb, ppos, c->tie_rule, pc_class_compare_only(l.base), ls, l.mode, c->max_gene_len);
         }
         if (rc != PC_OK) { first_error = rc; break; }
         if (stats) ++stats->n_align_launches;
-        slot = (slot + 1) % (n_aux + 1);
+        if (!(grp.key < 0 && region[grp.members[0]].own)) slot = (slot + 1) % (n_aux + 1);
     }
     // join the auxiliary streams back into the caller's stream -- also after a failed launch, so that what was
     // already queued on them is ordered before anything the caller does next
     for (int k = 0; k < n_aux; ++k) {
         PC_HIP(hipEventRecord(c->aux_ev[k], c->aux[k]));
         PC_HIP(hipStreamWaitEvent(st, c->aux_ev[k], 0));
+    }
+    for (int k = 0; k < n_long; ++k) {
+        PC_HIP(hipEventRecord(c->lng_ev[k], c->lng[k]));
+        PC_HIP(hipStreamWaitEvent(st, c->lng_ev[k], 0));
     }
     return first_error;
 }

@@ -171,6 +171,7 @@ int pc_nw_fuse_key(int variant, int max_lb, int ppos, int compare_only, int wave
 int pc_launch_nw_group(const PcNwSegment* segs, int nsegs, const PcDev& d, const PcTask* task_list, const int32_t* bucket_row,
                        const uint32_t* bucket_dest, uint2* res, int ppos, int tie_rule, hipStream_t st);
 size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu);    // scratch a strip-mined launch (max_lb > 64 x W of its variant) wants
+size_t pc_nw_strip_launch_bytes(int wave_mode, int ntasks, int max_row_len, int n_cu, int ppos);   // ... and one such launch with a region of its own
 int pc_nw_launch_is_strip(int variant, int max_lb, int wave_mode, int ppos);   // the launch runs on k_nw_strip and needs the scratch slab
 int pc_nw_strip_passes(int lb, int variant);                   // passes of 64 x W columns a column gene of lb residues takes on that variant (1: not strip-mined)
 size_t pc_nw_fallback_scratch_bytes(int max_lb);

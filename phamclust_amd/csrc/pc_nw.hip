@@ -115,6 +115,9 @@ PC_FOR_W1(PC_EXT1)
 #define PC_EXT_STRIP_R(W, INC, R) extern template int pc_strip_launch<W, R, INC> PC_STRIP_SIG;
 #define PC_EXT_STRIP(W, INC) PC_EXT_STRIP_R(W, INC, 2) PC_EXT_STRIP_R(W, INC, 3) PC_EXT_STRIP_R(W, INC, 4) PC_EXT_STRIP_R(W, INC, 5) PC_EXT_STRIP_R(W, INC, 6) PC_EXT_STRIP_R(W, INC, 7)
 PC_EXT_STRIP(32, false) PC_EXT_STRIP(48, false) PC_EXT_STRIP(64, false) PC_EXT_STRIP(24, true) PC_EXT_STRIP(8, false) PC_EXT_STRIP(12, false)
+#define PC_EXT_PIPE_R(W, R) extern template int pc_strip_launch<W, R, false, true> PC_STRIP_SIG;
+#define PC_EXT_PIPE(W) PC_EXT_PIPE_R(W, 2) PC_EXT_PIPE_R(W, 3) PC_EXT_PIPE_R(W, 4) PC_EXT_PIPE_R(W, 5) PC_EXT_PIPE_R(W, 6) PC_EXT_PIPE_R(W, 7)
+PC_EXT_PIPE(PC_STRIP_W_ONE_ROW)
 
 // columns-per-lane of the compiled systolic variants
 static const int g_variant_w[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 32, 48, 64};
@@ -420,19 +423,50 @@ size_t pc_nw_strip_scratch_bytes(int max_row_len, int n_cu) {
     if (blocks * per > budget) blocks = std::max<size_t>(budget / per, 8);
     return blocks * per;
 }
-template <int W, bool INC16>
+// Workgroup shape of a strip-mined launch: one row per wave (4 / 2 / 1 waves by the tasks' rows), or -- `pipe` -- the passes of one
+// alignment dealt over 8 or 4 waves, a workgroup per row (k_nw_strip's PIPE form).  A lone wave retires a 6,600 x 6,600 alignment in
+// T1 = 47 ms; eight waves in T1 / 6.4, four in T1 / 3.2, at 1 resp. 3 workgroups per CU instead of 11 one-wave ones.  So: the
+// pipeline while the launch's rows fit the chip in a round or two of it (the alignment's latency is then the launch's
+// duration, and on small fills the fill's), one row per wave beyond (more rows in flight, same instructions).
+// PC_PIPE=0: never; PC_PIPE=n: always, n waves.
+static int strip_launch_waves(int wave_mode, int ntasks, int ppos, int n_cu, bool& pipe) {
+    const char* env = getenv("PC_PIPE");                                  // (read per launch: the tests switch it between fills)
+    const int forced = env && *env ? atoi(env) : -1;
+    const int cu = n_cu > 0 ? n_cu : 256;
+    const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : PC_STRIP_WAVES;
+    pipe = false;
+    if (ppos || forced == 0) return nw;
+    if (forced > 0) { pipe = true; return forced < PC_PIPE_WAVES_MAX ? forced : PC_PIPE_WAVES_MAX; }
+    const long long rows = (long long)ntasks * nw;                       // (at most: a task of the 4- / 2- / 1-wave shape holds up to that many rows)
+    if (rows <= cu) { pipe = true; return PC_PIPE_WAVES_MAX; }
+    if (rows <= (wave_mode == PC_MODE_CLASS ? 3 : 6) * cu) { pipe = true; return 4; }
+    return nw;
+}
+// ... and of ONE strip-mined launch of `ntasks` tasks that gets a region of its own (run_align_classes: such launches then run side by
+// side, on their own streams, instead of one after the other on the one slab): a line per wave of as many workgroups as the
+// chip holds of that shape, or as the launch has tasks
+size_t pc_nw_strip_launch_bytes(int wave_mode, int ntasks, int max_row_len, int n_cu, int ppos) {
+    bool pipe; const int nw = strip_launch_waves(wave_mode, ntasks, ppos, n_cu, pipe);
+    const int per_cu = pipe ? (nw > 4 ? 1 : 3) : (nw == 1 ? 12 : nw == 2 ? 8 : 3);
+    size_t blocks = (size_t)per_cu * (size_t)(n_cu > 0 ? n_cu : 256);
+    const size_t units = (size_t)(ntasks > 0 ? ntasks : 1) * (pipe ? PC_STRIP_WAVES : 1);       // (pipelined: a workgroup per row)
+    if (blocks > units) blocks = units;
+    return blocks * strip_bytes_per_block(max_row_len, nw);
+}
+template <int W, bool INC16, bool PIPE = false>
 static int launch_strip(const PcDev& d, const PcTask* tasks, int ntasks, const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res,
                         void* scratch, size_t scratch_bytes, int max_row_len, int ppos, int rule, hipStream_t st, int nw = PC_STRIP_WAVES) {
     const size_t per = strip_bytes_per_block(max_row_len, nw);
     size_t blocks = scratch ? scratch_bytes / per : 0;
     if (blocks == 0) { pc_set_error("k_nw_strip<%d>: needs %zu bytes of scratch per workgroup", W, per); return PC_ERR_ARG; }
-    if (blocks > (size_t)ntasks) blocks = (size_t)ntasks;
+    if (blocks > (size_t)ntasks * (PIPE ? PC_STRIP_WAVES : 1)) blocks = (size_t)ntasks * (PIPE ? PC_STRIP_WAVES : 1);
     if (blocks > 4096) blocks = 4096;
     const size_t lines = INC16 ? (size_t)2 * ((pc_prof_rows(true) + 1) / 2) : (size_t)pc_prof_rows(false);
-    const size_t lds = (size_t)(144 + nw * pc_strip_wave_lds_dwords()) * 4 + lines * pc_prof_row_dwords(W, INC16) * 256;
+    const size_t lds = (size_t)(144 + nw * pc_strip_wave_lds_dwords()) * 4 + (PIPE ? (size_t)nw : (size_t)1) * lines * pc_prof_row_dwords(W, INC16) * 256;   // PIPE: a profile per wave
+    if (PIPE && (nw < 1 || nw > PC_PIPE_WAVES_MAX)) { pc_set_error("k_nw_strip<%d> (pipelined): %d waves", W, nw); return PC_ERR_ARG; }
     hipError_t e = hipSuccess;
     switch (rule) {
-#define PC_STRIP_CASE(R) case R: e = (hipError_t)pc_strip_launch<W, R, INC16>((unsigned)blocks, nw, lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, (uint4*)scratch, (unsigned)(max_row_len + 2)); break;
+#define PC_STRIP_CASE(R) case R: e = (hipError_t)pc_strip_launch<W, R, INC16, PIPE>((unsigned)blocks, nw, lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, (uint4*)scratch, (unsigned)(max_row_len + 2)); break;
     PC_STRIP_CASE(0) PC_STRIP_CASE(1) PC_STRIP_CASE(2) PC_STRIP_CASE(3) PC_STRIP_CASE(4) PC_STRIP_CASE(5) PC_STRIP_CASE(6) PC_STRIP_CASE(7)
 #undef PC_STRIP_CASE
     default: pc_set_error("tie rule %d out of range 0..7", rule); return PC_ERR_ARG;
@@ -460,7 +494,9 @@ int pc_launch_nw(int variant, const PcDev& d, const PcTask* tasks, int ntasks, c
         if (variant >= g_num_variants) { pc_set_error("pc_launch_nw: no variant %d", variant); return PC_ERR_ARG; }
         if (pc_nw_launch_is_strip(variant, max_lb, wave_mode, ppos)) {           // strip-mined passes (k_nw_strip)
             const int W = g_variant_w[variant];
-            const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : PC_STRIP_WAVES;
+            bool pipe; const int nw = strip_launch_waves(wave_mode, ntasks, ppos, d.n_cu, pipe);
+            // few tasks: the passes of each alignment over the waves of a workgroup, narrow passes whatever the class's width
+            if (pipe) return launch_strip<PC_STRIP_W_ONE_ROW, false, true>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st, nw);
             if (ppos && W == PC_INC16_MAX_W) return launch_strip<PC_INC16_MAX_W, true>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 1, rule, st, nw);
             // tasks of one row / two rows: narrow passes in one- / two-wave workgroups, whatever the class's own width
             if (!ppos && nw == 1) return launch_strip<PC_STRIP_W_ONE_ROW, false>(d, tasks, ntasks, bucket_row, bucket_dest, res, scratch, scratch_bytes, max_row_len, 0, rule, st, 1);

@@ -13,3 +13,5 @@ PC_FOR_W1(PC_INST1)
 // the strip-mined kernel (column genes beyond 64 x W columns): the three wide variants, and W = 24 with the profile cell (percent-positives)
 #define PC_INST_STRIP(W, INC) template int pc_strip_launch<W, PC_RULE_A, INC> PC_STRIP_SIG; template int pc_strip_launch<W, PC_RULE_B, INC> PC_STRIP_SIG;
 PC_INST_STRIP(32, false) PC_INST_STRIP(48, false) PC_INST_STRIP(64, false) PC_INST_STRIP(24, true) PC_INST_STRIP(8, false) PC_INST_STRIP(12, false)
+// ... and its pipelined form (the passes of one alignment over the workgroup's waves), narrow passes only
+template int pc_strip_launch<PC_STRIP_W_ONE_ROW, PC_RULE_A, false, true> PC_STRIP_SIG; template int pc_strip_launch<PC_STRIP_W_ONE_ROW, PC_RULE_B, false, true> PC_STRIP_SIG;

@@ -585,8 +585,19 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
 #define PC_STRIP_BND 64                                            // boundary entries a wave keeps staged (two refill windows)
 __host__ __device__ constexpr int pc_strip_wave_lds_dwords() { return 16 + PC_WIN + 4 * PC_STRIP_BND; }
 
-template <int W, int RULE, bool INC16>
-__global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_strip(PcDev d, const PcTask* __restrict__ tasks, int ntasks,
+// PIPE (r04, second form): the passes of ONE alignment spread over the workgroup's waves.  Wave w takes passes w, w + NWV, ... of the
+// task's rows, one row after the other; each wave builds the profile of its own pass (private LDS), writes its boundary line as
+// before, and the wave with the next pass reads it WHILE it is being written, 95+ row steps behind: every 32 steps a wave publishes
+// how far it is (one LDS word per wave: passes done << 17 | steps done, after a release fence), and a wave stages 32 boundary
+// entries only when the wave before it is 95 steps past them.  A wave never waits for the wave behind it (line reuse is safe:
+// pass p + NWV follows pass p + NWV - 1 by 64 steps, and so on down to pass p + 1, the reader of pass p's line), so the chain of
+// waits ends at pass 0 and the grid drains.  What it buys is LATENCY: a 6,600 x 6,600 alignment takes one wave 47 ms -- alone on
+// its SIMD it issues an instruction every ~12 clocks -- and a collection's few such alignments were the critical path of small
+// fills (synth_real(1000): 58 ms for 4.0e10 cells); over eight waves it takes an eighth.  Launches with many tasks keep the
+// one-row-per-wave form above, which holds more waves per CU.
+#define PC_PIPE_WAVES_MAX 8
+template <int W, int RULE, bool INC16, bool PIPE = false>
+__global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (W == 48 ? 2 : 1)) void k_nw_strip(PcDev d, const PcTask* __restrict__ tasks, int ntasks,
                                                                           const int32_t* __restrict__ bucket_row,
                                                                           const uint32_t* __restrict__ bucket_dest, uint2* __restrict__ res, int ppos,
                                                                           uint4* __restrict__ spill, unsigned spill_stride) {
@@ -610,30 +621,46 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
     uint32_t* wreg = smem + 144 + wv * pc_strip_wave_lds_dwords();
     uint32_t* ring = wreg + 16;                                    // [PC_WIN] staged stream entries
     uint32_t* bnd = ring + PC_WIN;                                 // [PC_STRIP_BND][4] staged boundary entries (Ho.hi, Ho.lo, E.hi, E.lo)
-    uint32_t* prof = smem + 144 + NWV * pc_strip_wave_lds_dwords();
+    constexpr int PROF_DW = (INC16 ? 2 * ((ROWS + 1) / 2) : ROWS) * RS * 64;     // one profile (PIPE: one per wave)
+    uint32_t* prof = smem + 144 + NWV * pc_strip_wave_lds_dwords() + (PIPE ? wv * PROF_DW : 0);
+    // PIPE: word 0 of a wave's region = its progress (passes done << 17 | row steps done of the pass it is in)
+    typedef __attribute__((address_space(3))) volatile uint32_t pc_lds_vu32;
+    pc_lds_vu32* const prog_me = (pc_lds_vu32*)(size_t)(__attribute__((address_space(3))) uint32_t*)wreg;
+    pc_lds_vu32* const prog_prev = (pc_lds_vu32*)(size_t)(__attribute__((address_space(3))) uint32_t*)(smem + 144 + ((wv + NWV - 1) % NWV) * pc_strip_wave_lds_dwords());
     const uint32_t kcol = (uint32_t)(lane < Gl ? lane : lane - Gl) + (lane < Gl ? 0u : half_dw);
     uint4* const line = spill + ((size_t)blockIdx.x * (size_t)NWV + (size_t)wv) * spill_stride;
+    // the line my left-hand boundary comes from: my own (the pass before was mine), PIPE: that of the wave with the pass before mine
+    const uint4* const line_in = PIPE ? spill + ((size_t)blockIdx.x * (size_t)NWV + (size_t)((wv + NWV - 1) % NWV)) * spill_stride : line;
     using TG = PcTag<RULE>;
     const uint32_t K = 0x10000u;
     const uint32_t prof_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)prof + kcol * 4u;
     const uint32_t v_nege = (uint32_t)(PC_NEG4 + TG::tE), v_zero = 0;
 
+    // a workgroup's unit of work: a task (one row per wave), PIPE: one ROW of a task (rows sub, sub + 4, ... of it: strip-mined tasks
+    // hold at most PC_STRIP_WAVES rows, so normally one) -- every alignment gets a pipeline of its own
+    constexpr int SUB = PIPE ? PC_STRIP_WAVES : 1;
 #pragma unroll 1
-    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    for (int unit = blockIdx.x; unit < ntasks * SUB; unit += gridDim.x) {
+        const int task = unit / SUB, sub = unit % SUB;
         const PcTask tk = tasks[task];
         const int lb_all = d.gene_len[tk.gene];
         const uint8_t* __restrict__ bp_all = d.codes + d.gene_off[tk.gene];
         const int npass = (lb_all + COLS - 1) / COLS;
         const int R = tk.end - tk.begin;                           // normally <= NWV rows: one round of one row per wave
 #pragma unroll 1
-        for (int r0 = 0; r0 < R; r0 += NWV) {
-        const int my_row = r0 + wv;
+        for (int r0 = (PIPE ? sub : 0); r0 < R; r0 += (PIPE ? SUB : NWV)) {
+        const int my_row = PIPE ? r0 : r0 + wv;                    // PIPE: every wave works on the same row
         const bool have_row = my_row < R;
         int la = 0; const uint8_t* ap = d.codes;
         if (have_row) { const int ga = bucket_row[tk.begin + my_row]; la = d.gene_len[ga]; ap = d.codes + d.gene_off[ga]; }
         const int seg_len = have_row ? la + 1 : 0;                 // the virtual row -1, then the la residues
+        if constexpr (PIPE) {
+            __syncthreads();                                       // score table visible; every wave is done with the row before (its lines, its progress word)
+            if (lane == 0) *prog_me = 0u;
+            __syncthreads();
+        }
 #pragma unroll 1
-        for (int pass = 0; pass < npass; ++pass) {
+        for (int pass = (PIPE ? wv : 0); pass < npass; pass += (PIPE ? NWV : 1)) {
             const int col0 = pass * COLS, lb = min(COLS, lb_all - col0);
             const uint8_t* __restrict__ bp = bp_all + col0;
             const int G = (lb + W - 1) / W;                        // lanes of this pass (64 in every pass but the last)
@@ -653,10 +680,10 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
                 }
                 bc[q] = v;
             }
-            __syncthreads();                                       // score table visible; every wave is done with the previous pass's profile
+            if constexpr (!PIPE) __syncthreads();                  // score table visible; every wave is done with the previous pass's profile
             if (in_seg) {
 #pragma unroll 1
-                for (int r = wv; r < ROWS; r += NWV) {
+                for (int r = (PIPE ? 0 : wv); r < ROWS; r += (PIPE ? 1 : NWV)) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q) {
                         uint32_t v = 0;
@@ -682,8 +709,9 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
                     }
                 }
             }
-            __syncthreads();                                       // profile of this pass complete
+            if constexpr (PIPE) pc_wave_lds_sync(); else __syncthreads();   // profile of this pass complete
             const int T = have_row ? seg_len + G - 1 : 0;
+            const uint32_t item = (uint32_t)(pass / NWV);          // PIPE: how many passes this wave has done before this one
             double Hou[W], Fu[W];
 #pragma unroll
             for (int c = 0; c < W; ++c) { Hou[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u); Fu[c] = pc_pack((uint32_t)(PC_NEG4 + TG::tF), 0u); }
@@ -692,6 +720,23 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
             uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
             const int hl = lane & (PC_WIN - 1);
             auto refill = [&](int base) {
+                if constexpr (PIPE) {
+                    // `base - 2` steps of this pass are done: their boundary entries first, then the word that says so
+                    // (both waves sit on one CU: the stores must have reached the L2 they share -- vmcnt counts stores on gfx9, and the
+                    // wait is spelled out because the compiler trimmed the fence's own down to lgkmcnt inside this loop -- and the reader's
+                    // loads bypass the L1; an agent-scope fence would also write the whole L2 back, every 32 steps)
+                    if (!last_pass && base >= 2) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) *prog_me = (item << 17) + (uint32_t)(base - 2);
+                    }
+                    // entries base .. base + 31 of the line I read were written at the other wave's steps base + 63 .. base + 94
+                    if (pass > 0 && base < seg_len) {
+                        const uint32_t need = ((uint32_t)((pass - 1) / NWV) << 17) + (uint32_t)base + 95u;     // (a finished pass counts as 1 << 17)
+                        while (*prog_prev < need) __builtin_amdgcn_s_sleep(4);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                }
                 pc_wave_lds_sync();
                 const uint32_t p = (uint32_t)base + (uint32_t)hl;
                 if (lane < PC_WIN) {                                // the stream entries of positions base .. base + 31
@@ -706,7 +751,7 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
                     }
                     ring[hl] = entry;
                 } else if (pass > 0 && p < (uint32_t)seg_len) {     // ... and the head's boundary for the same positions, from the pass before
-                    const unsigned long long* src = (const unsigned long long*)(line + p);
+                    const unsigned long long* src = (const unsigned long long*)(line_in + p);
                     const unsigned long long x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     *(uint4*)&bnd[(p & (PC_STRIP_BND - 1)) * 4] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
@@ -830,16 +875,21 @@ __global__ __launch_bounds__(64 * PC_STRIP_WAVES, (W == 48 ? 2 : 1)) void k_nw_s
                 step(t + 1, false, a2, a);
             }
             }
+            if constexpr (PIPE) if (!last_pass) {                  // the whole line is written: whoever reads it need not look at steps any more
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) *prog_me = (item + 1u) << 17;
+            }
         }
         }
         __syncthreads();                                           // the next task rebuilds the profile
     }
 }
 
-template <int W, int RULE, bool INC16>
+template <int W, int RULE, bool INC16, bool PIPE = false>
 int pc_strip_launch(unsigned nblocks, int nw, size_t lds, hipStream_t st, const PcDev& d, const PcTask* tasks, int ntasks,
                     const int32_t* bucket_row, const uint32_t* bucket_dest, uint2* res, int ppos, uint4* spill, unsigned spill_stride) {
-    hipLaunchKernelGGL((k_nw_strip<W, RULE, INC16>), dim3(nblocks), dim3(64 * nw), lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, spill, spill_stride);
+    hipLaunchKernelGGL((k_nw_strip<W, RULE, INC16, PIPE>), dim3(nblocks), dim3(64 * nw), lds, st, d, tasks, ntasks, bucket_row, bucket_dest, res, ppos, spill, spill_stride);
     return (int)hipGetLastError();
 }
 #define PC_STRIP_SIG (unsigned, int, size_t, hipStream_t, const PcDev&, const PcTask*, int, const int32_t*, const uint32_t*, uint2*, int, uint4*, unsigned)

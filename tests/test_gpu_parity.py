@@ -443,7 +443,8 @@ def test_strip_mined_long_column_genes(gpu_ctx, native_built):
     the reverse, a tie-heavy 3-letter alphabet among them, under tie rules 0 and 3 (the cyclic one carries two differently tagged
     copies of Ho across the pass boundary too): (n_ident, n_diag) equal the oracle's through the chooser and through each wide
     variant forced; aai / peq fills over genomes holding such genes, and percent-positives (profile cell, passes of 1,536
-    columns, column genes up to 8,191 residues) likewise."""
+    columns, column genes up to 8,191 residues) likewise.  Both forms of the kernel: one row per wave, and the passes of one
+    alignment pipelined over the waves of a workgroup (a wave reads the boundary line the wave before it is still writing)."""
     from phamclust_amd.genome import Genome
     from phamclust_amd.pack import pack_genomes
     O = _oracle()
@@ -480,15 +481,22 @@ def test_strip_mined_long_column_genes(gpu_ctx, native_built):
             O.set_tie_rule(rule)
             _, wi, wd = O.nw_batch(pk.residues, pk.seq_off, a, b)
             gpu_ctx.upload(pk)
-            for variant in (0, 32, 48, 64):
-                ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
-                assert np.array_equal(ident, wi) and np.array_equal(diag, wd), f"rule {rule} variant {variant}"
+            # PC_PIPE (read per launch): "0" one row per wave (the wide variants forced too); unset: the launcher's choice -- these few
+            # tasks run pipelined, the passes of each alignment dealt over eight waves; 4, 3 (passes not a multiple of the waves), 1
+            want_fill = {metric: O.fill(pk, metric) for metric in ("aai", "peq")}
+            for pipe in ("0", None, "4", "3", "1"):
+                if pipe is None: os.environ.pop("PC_PIPE", None)
+                else: os.environ["PC_PIPE"] = pipe
+                for variant in ((0, 32, 48, 64) if pipe == "0" else (0, 48)):
+                    ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
+                    assert np.array_equal(ident, wi) and np.array_equal(diag, wd), f"rule {rule} variant {variant} PC_PIPE {pipe}"
+                for metric in ("aai", "peq"):
+                    assert np.array_equal(gpu_ctx.fill(metric), want_fill[metric]), f"rule {rule} {metric} PC_PIPE {pipe}"
+            os.environ.pop("PC_PIPE", None)
             if rule == 0:
                 sel = (lens_all[b] < 5500) & (lens_all[a] < 5500)          # the one-lane-per-alignment kernel agrees (it stays as the fallback;
                 ident, diag = gpu_ctx.align_pairs(a[sel], b[sel], variant=-1)   # 3 x 10^7 cells on ONE lane take seconds: only the shorter pairs)
                 assert sel.sum() >= 10 and np.array_equal(ident, wi[sel]) and np.array_equal(diag, wd[sel])
-            for metric in ("aai", "peq"):
-                assert np.array_equal(gpu_ctx.fill(metric), O.fill(pk, metric)), f"rule {rule} {metric}"
             # percent-positives: the profile cell, passes of 64 x 24 columns, for column genes of 1,537 ... 8,191 residues
             gpu_ctx.upload(pk_ppos)
             assert np.array_equal(gpu_ctx.fill("aai_ppos"), O.fill(pk_ppos, "aai_ppos")), f"rule {rule} aai_ppos"
@@ -496,6 +504,7 @@ def test_strip_mined_long_column_genes(gpu_ctx, native_built):
             _, wi, wd = O.nw_batch(pk_ppos.residues, pk_ppos.seq_off, a_pp, b_pp)
             assert np.array_equal(ident, wi) and np.array_equal(diag, wd)
     finally:
+        os.environ.pop("PC_PIPE", None)
         O.set_tie_rule(0)
         gpu_ctx.set_tie_rule(0)
 
@@ -1539,7 +1548,8 @@ def test_real_collection_shape_full_matrix(gpu_ctx, native_built):
 
 def test_launch_policy_switches_change_no_value(native_built):
     """The r04 launch machinery -- tier launches (PC_FUSE), one- / two-wave workgroups for small tasks (PC_SMALL_MODES, fold
-    threshold PC_SMALL_LAUNCH_MIN), strip-mined passes (PC_STRIP) -- is policy: every setting must give the oracle's matrix
+    threshold PC_SMALL_LAUNCH_MIN), strip-mined passes (PC_STRIP), the strip-mined launches' slab regions and streams
+    (PC_STRIP_STREAMS, PC_SLAB_BUDGET: side by side, in line on the caller's stream, or some of each) -- is policy: every setting must give the oracle's matrix
     (metrics.py:178-253) and differ only in how many launches it takes.  The switches are read once per process, so each
     setting runs in a process of its own, on a collection with small and large buckets and a few genes beyond 4,096 residues."""
     import json
@@ -1561,7 +1571,8 @@ with hip.Context(0) as ctx:
     print(json.dumps({"launches": st["n_align_launches"], "tasks": st["n_tasks"]}))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = {}
-    for name, env in (("default", {}), ("per_class", {"PC_FUSE": "0", "PC_SMALL_LAUNCH_MIN": "1"}), ("no_modes_no_strip", {"PC_SMALL_MODES": "0", "PC_STRIP": "0"})):
+    for name, env in (("default", {}), ("per_class", {"PC_FUSE": "0", "PC_SMALL_LAUNCH_MIN": "1"}), ("no_modes_no_strip", {"PC_SMALL_MODES": "0", "PC_STRIP": "0"}),
+                      ("strips_in_line", {"PC_STRIP_STREAMS": "0"}), ("one_strip_region_fits", {"PC_SLAB_BUDGET": "300000"})):
         run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert run.returncode == 0, (name, run.stdout[-1500:], run.stderr[-3000:])
         seen[name] = json.loads(run.stdout.strip().splitlines()[-1])

@@ -9,8 +9,8 @@ upload, both popcount tile kernels (PC_POPC_TILE, read per launch), every pocp /
 the same pairs of the unsharded matrix: see profiles/r03/final/stress.txt.
 r04: one collection in twelve holds genes of 4,100-8,100 residues (strip-mined passes on the wide and the narrow variants, the
 percent-positives passes), PC_S64_CHUNKS is drawn per collection, and buckets of one or
-two rows -- most of what these tiny collections hold -- take the one- / two-wave workgroups and the tier launches: see
-profiles/r04/final/stress.txt."""
+two rows -- most of what these tiny collections hold -- take the one- / two-wave workgroups and the tier launches; the strip-mined
+launches run one row per wave or pipelined over 2 / 3 / 8 waves (PC_PIPE, drawn per collection): see profiles/r04/final/stress.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -50,6 +50,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
     os.environ["PC_POPC_TILE"] = str(rng.choice(["32", "64"]))
     os.environ["PC_SET_KERNEL"] = str(rng.choice(["popc", "sparse", "sparse64", "walker"]))   # pocp / af kernel, read per fill
     os.environ["PC_S64_CHUNKS"] = str(rng.choice(["1", "2", "3"]))
+    os.environ["PC_PIPE"] = str(rng.choice(["", "0", "2", "3", "8"]))       # strip-mined launches: the launcher's choice, one row per wave, pipelined over n waves
     for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
         got = ctx.fill(metric, as_distance=bool(trial & 1))
         want = O.fill(packed, metric, as_distance=bool(trial & 1))
