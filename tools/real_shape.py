@@ -14,6 +14,7 @@ ap.add_argument("-n", type=int, default=5000)
 ap.add_argument("--check", type=int, default=3000)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--out", default="")
+ap.add_argument("--also", default="1000,2000", help="smaller collections of the same shape: peq only (where a few long alignments would be the fill's critical path), with the strip-mined launches one row per wave beside the default")
 a = ap.parse_args()
 build.build_all()
 t0 = time.time(); pk = synth_real(a.n); t_gen = time.time() - t0
@@ -63,6 +64,27 @@ for metric in ("gcs", "jc", "pocp", "af", "aai", "peq"):
         row["fastest"] = min(forced, key=forced.get)
     rec["metrics"][metric] = row
     print(metric, json.dumps(row), flush=True)
+rec["peq_at_other_sizes"] = {}
+for n2 in [int(x) for x in a.also.split(",") if x]:
+    pk2 = synth_real(n2)
+    ctx.upload(pk2)
+    out2 = torch.empty(pk2.n_pairs, dtype=torch.float64, device="cuda")
+    row = {}
+    for label, pipe in (("default", None), ("PC_PIPE=0", "0")):
+        if pipe is None: os.environ.pop("PC_PIPE", None)
+        else: os.environ["PC_PIPE"] = pipe
+        best = min((ctx.fill_dev("peq", True, out2.data_ptr(), stream) for _ in range(a.steps)), key=lambda st: st["ms_total"])
+        torch.cuda.synchronize()
+        row[label] = {"ms": best["ms_total"], "ms_align": best["ms_align"], "n_distinct_cells": best["n_distinct_cells"],
+                      "tcups_distinct": best["n_distinct_cells"] / max(best["ms_align"], 1e-9) / 1e9, "n_launches": best["n_align_launches"]}
+    os.environ.pop("PC_PIPE", None)
+    r2 = np.random.default_rng(6)
+    s2 = r2.integers(0, n2 - 1, 600); t2 = r2.integers(0, n2, 600)
+    lo2, hi2 = np.minimum(s2, t2), np.maximum(s2, t2); k2 = lo2 < hi2; lo2, hi2 = lo2[k2], hi2[k2]
+    got2 = out2[torch.as_tensor(lo2 * n2 - lo2 * (lo2 + 1) // 2 + (hi2 - lo2 - 1), device="cuda")].cpu().numpy()
+    row["bit_exact"] = bool(np.array_equal(got2, O.pairs(pk2, "peq", lo2, hi2, as_distance=True))); row["oracle_pairs"] = int(lo2.size)
+    rec["peq_at_other_sizes"][str(n2)] = row
+    print("peq", n2, json.dumps(row), flush=True)
 if a.out:
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rec, open(a.out, "w"), indent=1)
