@@ -128,6 +128,20 @@ __device__ __forceinline__ double pc_pack(uint32_t hi, uint32_t lo) { return __h
 __device__ __forceinline__ uint32_t pc_hi(double v) { return (uint32_t)__double2hiint(v); }
 __device__ __forceinline__ uint32_t pc_lo(double v) { return (uint32_t)__double2loint(v); }
 __device__ __forceinline__ double pc_retag(double v, uint32_t tag) { return pc_pack((pc_hi(v) & ~3u) | tag, pc_lo(v)); }
+// Re-tag the result of max(x [tag FROM], y [tag TO]) -- its tag is one of the two -- as TO.  Where one of the tags' bits contain the
+// other's, that is ONE VOP2 instruction (v_or_b32 / v_and_b32 with an inline constant) instead of the VOP3 v_and_or_b32: the plain
+// 32-bit logic and add instructions are the ones a SIMD retires two of per 4 clocks when several waves share it
+// (profiles/valu_issue_rate.txt: ~2.2 clocks against 4.2 for v_max_f64 / SDWA / VOP3 forms; ~3.5 in the cell's mix).  Rule 0 (the
+// production rule: tags O 0, E 1, F 2): both re-tags are an OR.
+#ifndef PC_RETAG_ONE_OP
+#define PC_RETAG_ONE_OP 1
+#endif
+template <int FROM, int TO>
+__device__ __forceinline__ double pc_retag_from(double v) {
+    if constexpr (PC_RETAG_ONE_OP && (FROM | TO) == TO) return pc_pack(pc_hi(v) | (uint32_t)TO, pc_lo(v));
+    else if constexpr (PC_RETAG_ONE_OP && (FROM & TO) == TO) return pc_pack(pc_hi(v) & (~3u | (uint32_t)TO), pc_lo(v));
+    else return pc_retag(v, (uint32_t)TO);
+}
 
 // One cell.  In: D (this cell's diagonal candidate, tag 3), chain values HoL [tag tOF] and EL [tE], row code ac.
 // In/out (in place): column state Hou -> Ho, Fu -> F.  Out: E (chain), and for the next cell Dn = old Hou + score of the
@@ -175,8 +189,8 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
         else PC_CELL64_A("BYTE_3");
 #undef PC_CELL64_A
     }
-    E = pc_retag(E, T::tE);
-    Fu = pc_retag(Fu, T::tF);
+    E = pc_retag_from<T::tOE, T::tE>(E);             // E came from HoL [tOE] or EL [tE]
+    Fu = pc_retag_from<T::tOF, T::tF>(Fu);           // F from Hou [tOF] or Fu [tF]
     double H;
     asm("v_max_f64 %0, %1, %2\n\tv_max_f64 %0, %0, %3" : "=&v"(H) : "v"(D), "v"(Fu), "v"(E));
     Hou = pc_pack((pc_hi(H) & ~3u) + (uint32_t)(T::tOF - 40), pc_lo(H));

@@ -10,9 +10,11 @@ import weakref
 
 import numpy as np
 
-# PHAMCLUST_NATIVE_VARIANT=hooks loads the twin compiled with -DPC_TEST_HOOKS (fault injection; one GPU test runs on it)
+# PHAMCLUST_NATIVE_VARIANT=hooks loads the twin compiled with -DPC_TEST_HOOKS (fault injection; one GPU test runs on it); any other
+# name but "asan" (the host libraries' sanitized twins) loads csrc/libphamclust_hip_<name>.so -- A/B of two builds in one GPU call
+_variant = os.environ.get("PHAMCLUST_NATIVE_VARIANT", "")
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
-                        "libphamclust_hip_hooks.so" if os.environ.get("PHAMCLUST_NATIVE_VARIANT") == "hooks" else "libphamclust_hip.so")
+                        f"libphamclust_hip_{_variant}.so" if _variant not in ("", "asan") else "libphamclust_hip.so")
 METRIC_IDS = {"gcs": 0, "jc": 1, "pocp": 2, "af": 3, "aai": 4, "peq": 5, "aai_ppos": 6}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
