@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "pc_common.h"
 #include "../../include/phamclust_hip.h"
@@ -148,7 +149,7 @@ __device__ __forceinline__ double pc_retag_from(double v) {
 // next cell (+ 3 - tOF, folded into the profile byte) with statistics old Hou's + 0x10000 + (ac == bcn).
 // The first block is asm because of its SDWA forms and because v_cmp's SGPR result must not be read by v_addc sooner than
 // two instructions later (gfx950; nothing pads inside asm): the two independent v_max_f64 sit in between.
-template <int NEXT_COL, int RULE, bool INC16>
+template <int NEXT_COL, int RULE, bool INC16, bool U8 = false>
 __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, double& Hou, double& Fu, double& E, double& Dn,
                                           uint32_t ac, uint32_t bcn, uint32_t pwn, uint32_t pmn, uint32_t K) {
     using T = PcTag<RULE>;
@@ -158,6 +159,15 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
     uint32_t dn_hi = 0, dn_lo = 0;
     if constexpr (NEXT_COL < 0) {
         asm("v_max_f64 %[E], %[HoL], %[EL]\n\tv_max_f64 %[Fu], %[Hou], %[Fu]" : [E] "=&v"(E), [Fu] "+v"(Fu) : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou));
+    } else if constexpr (INC16 && U8) {
+        // PC_PROF_U8: the LDS did the byte / word select (ds_read_u8, ds_read_u16): `pwn` IS the next column's score entry, `pmn` its
+        // statistics increment, and both adds are plain VOP2 -- the fast issue class (see pc_retag_from)
+        asm("v_max_f64 %[E], %[HoL], %[EL]\n\t"
+            "v_max_f64 %[Fu], %[Hou], %[Fu]\n\t"
+            "v_add_u32 %[dh], %[pwn], %[ohi]\n\t"
+            "v_add_u32 %[dl], %[pmn], %[olo]"
+            : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo)
+            : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn));
     } else if constexpr (INC16) {
         // the statistics' increment comes from the profile too: a 16-bit entry 0x2000 + (row residue == column residue)
 #define PC_CELL64_B(SEL, WSEL)                                                                                         \
@@ -230,6 +240,57 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C + 1 < W) PcRow<W, C + 1, RULE, INC16>::run(Dn, Hou[C], E, Hou, Fu, bc, pw, pm, nxt, ac, K, E_out);
+        else E_out = E;
+    }
+};
+
+// PC_PROF_U8 (r04): the profile cell's operands read from LDS one COLUMN at a time -- ds_read_u8 of the score byte, ds_read_u16 of
+// the increment, same table, same addresses -- so that the two adds of a cell are plain VOP2 instead of SDWA (the fast issue class:
+// see pc_retag_from).  Entry m of a row (m = 0: the step prologue's, m >= 1: cell m - 1's "next column") lives in one of TWO slots,
+// (m + W x step parity) & 1, and a slot is re-loaded right after the instruction that read it with the entry two further on -- of
+// this row, or, for a row's last two, of the next row (`nxt`): every load is two cells ahead of its use, and 4 registers replace
+// W/4 + W/2.  The slots are 32-bit: a narrower operand cannot be a "v" operand, and the compiler masks (v_and_b32 0xff / 0xffff)
+// only what crosses a branch or the loop's back edge -- the four entries in flight at a step boundary (a slot per entry, as a
+// first version had it, crossed with ten).
+// MEASURED AND NOT TAKEN (profiles/r04/experiments/profile_u8_reads_ab.txt): bit-exact, 6-18 registers fewer, and SLOWER --
+// synth(5000,5000) peq 550 -> 559 ms, N = 2,000 117.5 -> 120.5; uniform 420-residue genes (8-wave workgroups) 3,172 -> 2,692 GCUPS:
+// two LDS instructions per cell (against 0.75) cost more at the LDS than the two SDWA adds cost at the VALU.  Kept compiled out.
+#ifndef PC_PROF_U8
+#define PC_PROF_U8 0
+#endif
+typedef __attribute__((address_space(3))) const uint8_t pc_lds_u8;
+typedef __attribute__((address_space(3))) const uint16_t pc_lds_u16;
+template <int W>
+struct PcU8 {
+    static constexpr int ND = (W + 3) / 4;
+    static __host__ __device__ constexpr int slot(int m, int par) { return (m + par * W) & 1; }
+    static __device__ __forceinline__ uint32_t score(uint32_t row, int m) { return (uint32_t)*(pc_lds_u8*)(size_t)(row + (uint32_t)((m >> 2) * 256 + (m & 3))); }
+    static __device__ __forceinline__ uint32_t incr(uint32_t row, int m) { return (uint32_t)*(pc_lds_u16*)(size_t)(row + (uint32_t)((ND + (m >> 1)) * 256 + (m & 1) * 2)); }
+    // entry M of a row of parity PAR has just been read: what its slot holds next
+    template <int M, int PAR>
+    static __device__ __forceinline__ void reload(uint32_t (&sc)[2], uint32_t (&in)[2], uint32_t cur, uint32_t nxt) {
+        constexpr int S = slot(M, PAR);
+        if constexpr (M + 2 <= W - 1) { sc[S] = score(cur, M + 2); in[S] = incr(cur, M + 2); }
+        else { sc[S] = score(nxt, M + 2 - W); in[S] = incr(nxt, M + 2 - W); static_assert(slot(M + 2 - W, PAR ^ 1) == S, "slot parity"); }
+    }
+    static __device__ __forceinline__ void first(uint32_t (&sc)[2], uint32_t (&in)[2], uint32_t row) {      // row of parity 0
+        sc[0] = score(row, 0); in[0] = incr(row, 0); sc[1] = score(row, 1); in[1] = incr(row, 1);
+    }
+};
+template <int W, int C, int RULE, int PAR>
+struct PcRowU8 {
+    using U = PcU8<W>;
+    static __device__ __forceinline__ void run(double D, double HoL, double EL, double (&Hou)[W], double (&Fu)[W],
+                                               uint32_t (&sc)[2], uint32_t (&in)[2], uint32_t cur, uint32_t nxt, double& E_out) {
+        double E, Dn;
+        constexpr int N = (C + 1 < W) ? C + 1 : -1;
+        pc_cell64<N, RULE, true, true>(D, HoL, EL, Hou[C], Fu[C], E, Dn, 0u, 0u, sc[N < 0 ? 0 : U::slot(N, PAR)], in[N < 0 ? 0 : U::slot(N, PAR)], 0u);
+        if constexpr (N >= 0) {
+            __builtin_amdgcn_sched_barrier(0);           // load here, into the registers that have just died
+            U::template reload<N, PAR>(sc, in, cur, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (C + 1 < W) PcRowU8<W, C + 1, RULE, PAR>::run(Dn, Hou[C], E, Hou, Fu, sc, in, cur, nxt, E_out);
         else E_out = E;
     }
 };
@@ -456,8 +517,14 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
     uint32_t a = is_head ? ring[ring_lane] : 0u;
     uint32_t e_nxt = ring[ring_lane + 1];                          // head's entry for step 1 (PC_WIN >= 2)
     uint32_t e_b = 0;                                              // entry t+3 (entries t+2, t+3 are fetched as a pair on even steps)
-    uint32_t pw[ND], pm[INC16 ? NDM : 1];                          // this row's score bytes and statistics increments
-    {
+    constexpr bool U8 = INC16 && PC_PROF_U8;                       // profile operands by ds_read_u8 / _u16, one column at a time (PcRowU8)
+    uint32_t pw[U8 ? 1 : ND], pm[(INC16 && !U8) ? NDM : 1];        // this row's score bytes and statistics increments
+    uint32_t u_sc[2], u_in[2], u_cur = 0;   // U8: the entries in flight, and this row's strip address
+    if constexpr (U8) {
+        u_cur = row_addr(a);
+        PcU8<W>::first(u_sc, u_in, u_cur);
+        pw[0] = 0; pm[0] = 0;
+    } else {
         pc_lds_u32* r0 = (pc_lds_u32*)(size_t)row_addr(a);
 #pragma unroll
         for (int q = 0; q < ND; ++q) pw[q] = r0[q * 64];
@@ -473,7 +540,9 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
     uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
 
     // One row step.  `a` is this step's stream entry, `a_nxt` receives the next step's.
-    auto step = [&](int t, const bool even, uint32_t a, uint32_t& a_nxt) {
+    auto step = [&](int t, auto even_tag, uint32_t a, uint32_t& a_nxt) {
+        constexpr bool even = decltype(even_tag)::value;
+        constexpr int PAR = even ? 0 : 1;                                 // row parity (U8 slot assignment)
         if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         // Step prologue, 9 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
         // k-1's value (DPP wave_shr:1 on src0, executed with every lane active), head lanes (vcc) take src1 = their
@@ -483,7 +552,26 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
         // K.BYTE_2 == 1.
         uint32_t HoL_hi, HoL_lo, EL_hi, EL_lo, D0_hi, D0_lo;
         unsigned long long anym;
-        if constexpr (INC16) {
+        if constexpr (U8) {
+            asm volatile(
+                "s_nop 1\n\t"
+                "s_mov_b64 vcc, %[hm]\n\t"
+                "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Hh], %[Hwh], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cmp_ne_u32_sdwa %[anym], %[a], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+                "v_add_u32 %[D0h], %[pw0], %[Hodh]\n\t"                     // column 0's entries are whole dwords here
+                "v_add_u32 %[D0l], %[pm0], %[Hodl]\n\t"
+                "s_and_b64 %[anym], %[anym], %[hom]\n\t"
+                : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
+                  [D0l] "=&v"(D0_lo), [anym] "=&s"(anym)
+                : [hm] "s"(headm), [hom] "s"(headoutm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
+                  [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [pw0] "v"(u_sc[PcU8<W>::slot(0, PAR)]), [pm0] "v"(u_in[PcU8<W>::slot(0, PAR)]),
+                  [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
+                : "vcc", "scc");
+        } else if constexpr (INC16) {
             asm volatile(
                 "s_nop 1\n\t"                                               // VALU (previous step's cells) -> DPP read: 2 wait states
                 "s_mov_b64 vcc, %[hm]\n\t"
@@ -524,7 +612,13 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
                   [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
                 : "vcc", "scc");
         }
-        pc_lds_u32* nxt = (pc_lds_u32*)(size_t)row_addr(a_nxt);          // the next row's strip
+        const uint32_t nxt_addr = row_addr(a_nxt);                        // the next row's strip
+        pc_lds_u32* nxt = (pc_lds_u32*)(size_t)nxt_addr;
+        if constexpr (U8) {
+            __builtin_amdgcn_sched_barrier(0);
+            PcU8<W>::template reload<0, PAR>(u_sc, u_in, u_cur, nxt_addr);   // the prologue has read entry 0
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (even) {                                                       // the head's entries for steps t+2 and t+3
             const uint2 e2 = *(const uint2*)&ring[ring_lane + ((t + 2) & (PC_WIN - 1))];
             e_nxt = e2.x; e_b = e2.y;
@@ -549,7 +643,10 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
         }
         const double HoL = pc_pack(HoL_hi, HoL_lo);
         p_HoL = HoL;
-        PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
+        if constexpr (U8) {
+            PcRowU8<W, 0, RULE, PAR>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, u_sc, u_in, u_cur, nxt_addr, o_E);
+            u_cur = nxt_addr;
+        } else PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
         asm volatile("" : "+s"(lastm));                                   // test here, not 140 instructions earlier (the compiler would carry the result as a lane mask: one VALU compare)
         if (lastm != 0) {                                                 // a row's last cell left the lane holding column lb-1
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own
@@ -566,8 +663,8 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
     uint32_t a2 = 0;
 #pragma unroll 1
     for (int t = 0; t < T; t += 2) {
-        step(t, true, a, a2);
-        step(t + 1, false, a2, a);
+        step(t, std::true_type{}, a, a2);
+        step(t + 1, std::false_type{}, a2, a);
     }
 }
 
