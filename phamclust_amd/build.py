@@ -18,11 +18,14 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # (source, object, extra flags): the systolic alignment kernel's tie rules are spread over four translation units
+# tools/build_variant.py adds -ffinite-math-only to these units for the builds that use __builtin_fmax on the cell's 64-bit words
+# (PC_MAX_BUILTIN / PC_CELL_ORDER: experiment switches of pc_nw_systolic.h); the product build uses asm maxima and needs no flag.
+NW_FLAGS = []
 HIP_UNITS = [("pc_api.hip", "pc_api.o", []), ("pc_pairs.hip", "pc_pairs.o", []), ("pc_plan.hip", "pc_plan.o", []),
-             ("pc_nw.hip", "pc_nw.o", []),
-             ("pc_nw_rules.hip", "pc_nw_r23.o", ["-DPC_RULE_A=2", "-DPC_RULE_B=3"]),
-             ("pc_nw_rules.hip", "pc_nw_r45.o", ["-DPC_RULE_A=4", "-DPC_RULE_B=5"]),
-             ("pc_nw_rules.hip", "pc_nw_r67.o", ["-DPC_RULE_A=6", "-DPC_RULE_B=7"])]
+             ("pc_nw.hip", "pc_nw.o", NW_FLAGS),
+             ("pc_nw_rules.hip", "pc_nw_r23.o", NW_FLAGS + ["-DPC_RULE_A=2", "-DPC_RULE_B=3"]),
+             ("pc_nw_rules.hip", "pc_nw_r45.o", NW_FLAGS + ["-DPC_RULE_A=4", "-DPC_RULE_B=5"]),
+             ("pc_nw_rules.hip", "pc_nw_r67.o", NW_FLAGS + ["-DPC_RULE_A=6", "-DPC_RULE_B=7"])]
 # the same library once more with pc_api.hip compiled under -DPC_TEST_HOOKS (fault injection: PC_FAKE_OOM_ABOVE); every other
 # object is shared.  Loaded only by the test that needs it (PHAMCLUST_NATIVE_VARIANT=hooks).
 HOOKS_UNIT = ("pc_api.hip", "pc_api_hooks.o", ["-DPC_TEST_HOOKS"])

@@ -144,6 +144,17 @@ __device__ __forceinline__ double pc_retag_from(double v) {
     else return pc_retag(v, (uint32_t)TO);
 }
 
+// PC_MAX_BUILTIN (experiment switch, off): the lexicographic maxima as the compiler's own v_max_f64 (__builtin_fmax; such builds
+// compile the alignment units with -ffinite-math-only -- tools/build_variant.py -- so that no canonicalising v_max_f64 x, x, x
+// precedes them: every value here is a positive normal double by construction) instead of inline asm.  The idea: a VALU
+// instruction that reads a register DEFINED BY INLINE ASM right after it gets an `s_nop 0` from the compiler (it must assume the
+// asm used an SDWA destination select) -- two per cell, for hazards that are not there.  MEASURED: without them the fill is 5 %
+// SLOWER (551 -> 580 ms, profiles/r04/experiments/builtin_max_ab.txt); PC_CELL_ORDER below says why.
+#ifndef PC_MAX_BUILTIN
+#define PC_MAX_BUILTIN 0
+#endif
+__device__ __forceinline__ double pc_max64(double a, double b) { return __builtin_fmax(a, b); }
+
 // One cell.  In: D (this cell's diagonal candidate, tag 3), chain values HoL [tag tOF] and EL [tE], row code ac.
 // In/out (in place): column state Hou -> Ho, Fu -> F.  Out: E (chain), and for the next cell Dn = old Hou + score of the
 // next cell (+ 3 - tOF, folded into the profile byte) with statistics old Hou's + 0x10000 + (ac == bcn).
@@ -157,7 +168,10 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
     if constexpr (T::cyclic) HoL = pc_pack(pc_hi(HoL) + (uint32_t)(T::tOE - T::tOF), pc_lo(HoL));
     const uint32_t ohi = pc_hi(Hou), olo = pc_lo(Hou);
     uint32_t dn_hi = 0, dn_lo = 0;
-    if constexpr (NEXT_COL < 0) {
+    if constexpr (NEXT_COL < 0 && PC_MAX_BUILTIN) {
+        E = pc_max64(HoL, EL);
+        Fu = pc_max64(Hou, Fu);
+    } else if constexpr (NEXT_COL < 0) {
         asm("v_max_f64 %[E], %[HoL], %[EL]\n\tv_max_f64 %[Fu], %[Hou], %[Fu]" : [E] "=&v"(E), [Fu] "+v"(Fu) : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou));
     } else if constexpr (INC16 && U8) {
         // PC_PROF_U8: the LDS did the byte / word select (ds_read_u8, ds_read_u16): `pwn` IS the next column's score entry, `pmn` its
@@ -177,11 +191,23 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
         "v_add_u32_sdwa %[dl], %[pmn], %[olo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" WSEL " src1_sel:DWORD"    \
         : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo)                                            \
         : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn))
-        if constexpr (NEXT_BYTE == 0) PC_CELL64_B("BYTE_0", "WORD_0");
+#define PC_CELL64_ADDS(SEL, WSEL)                                                                                      \
+    asm("v_add_u32_sdwa %[dh], %[pwn], %[ohi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
+        "v_add_u32_sdwa %[dl], %[pmn], %[olo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" WSEL " src1_sel:DWORD"    \
+        : [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo) : [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn))
+        if constexpr (PC_MAX_BUILTIN) {
+            if constexpr (NEXT_BYTE == 0) PC_CELL64_ADDS("BYTE_0", "WORD_0");
+            else if constexpr (NEXT_BYTE == 1) PC_CELL64_ADDS("BYTE_1", "WORD_1");
+            else if constexpr (NEXT_BYTE == 2) PC_CELL64_ADDS("BYTE_2", "WORD_0");
+            else PC_CELL64_ADDS("BYTE_3", "WORD_1");
+            E = pc_max64(HoL, EL);
+            Fu = pc_max64(Hou, Fu);
+        } else if constexpr (NEXT_BYTE == 0) PC_CELL64_B("BYTE_0", "WORD_0");
         else if constexpr (NEXT_BYTE == 1) PC_CELL64_B("BYTE_1", "WORD_1");
         else if constexpr (NEXT_BYTE == 2) PC_CELL64_B("BYTE_2", "WORD_0");
         else PC_CELL64_B("BYTE_3", "WORD_1");
 #undef PC_CELL64_B
+#undef PC_CELL64_ADDS
     } else {
         unsigned long long c2;
 #define PC_CELL64_A(SEL)                                                                                               \
@@ -202,7 +228,8 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
     E = pc_retag_from<T::tOE, T::tE>(E);             // E came from HoL [tOE] or EL [tE]
     Fu = pc_retag_from<T::tOF, T::tF>(Fu);           // F from Hou [tOF] or Fu [tF]
     double H;
-    asm("v_max_f64 %0, %1, %2\n\tv_max_f64 %0, %0, %3" : "=&v"(H) : "v"(D), "v"(Fu), "v"(E));
+    if constexpr (PC_MAX_BUILTIN) H = pc_max64(pc_max64(D, Fu), E);
+    else asm("v_max_f64 %0, %1, %2\n\tv_max_f64 %0, %0, %3" : "=&v"(H) : "v"(D), "v"(Fu), "v"(E));
     Hou = pc_pack((pc_hi(H) & ~3u) + (uint32_t)(T::tOF - 40), pc_lo(H));
     Dn = pc_pack(dn_hi, dn_lo);
 }
@@ -240,6 +267,106 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C + 1 < W) PcRow<W, C + 1, RULE, INC16>::run(Dn, Hou[C], E, Hou, Fu, bc, pw, pm, nxt, ac, K, E_out);
+        else E_out = E;
+    }
+};
+
+// PC_CELL_ORDER (r04, experiment harness): the profile cell's sweep with the maxima as compiler instructions and the ORDER of the ten
+// instructions pinned from the source (a scheduling barrier after each), to find out what the hand-placed asm blocks of pc_cell64 owe
+// to their order and what to the two `s_nop 0` the compiler puts behind them (the plain builtin form -- same instructions, no
+// s_nop, compiler's order -- is 5 % SLOWER: profiles/r04/experiments/builtin_max_ab.txt).
+//   1: pc_cell64's order, no s_nop      2: pc_cell64's order with its two s_nop 0
+//   3: software-pipelined -- the next cell's independent work (its F maximum, its diagonal-term adds) between the links of the
+//      dependent chain E -> re-tag -> H -> Ho, no s_nop      4: the same with an s_nop 0 ahead of the Ho fix-up
+//   5-9: pc_cell64's order with s_nop 0 at other sets of positions (see PcRowS::run)
+// MEASURED (profiles/r04/experiments/cell_order_and_nops_ab.txt; N = 2,000 fill, alignment ms): asm blocks (= order 2) 117.4 | 1: 123.2 |
+// 2: 118.7 | 3: 122.8 | 4: 119.2 | 5: 119.6 | 6: 121.7 | 7: 119.8 | 8: 118.3 | 9: 120.7.  The ORDER is worth nothing (1 = 3, 2 = 4): what
+// the asm blocks owe their 4.5 % to is the compiler's two s_nop 0 -- a pause of the WAVE ahead of a 32-bit instruction that reads a
+// v_max_f64 result (an independent VALU instruction in the same place does not do it: 3), and more pauses only cost (5, 6, 7).
+// So the product stays on pc_cell64's asm blocks; this harness is compiled out.
+#ifndef PC_CELL_ORDER
+#define PC_CELL_ORDER 0
+#endif
+#define PC_SB() __builtin_amdgcn_sched_barrier(0)
+template <int N>
+__device__ __forceinline__ uint32_t pc_dn_hi(uint32_t pw, uint32_t ohi) {        // hi of column N's diagonal term: old Ho of column N - 1 + score byte
+    uint32_t d;
+    if constexpr ((N & 3) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
+    else if constexpr ((N & 3) == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
+    else if constexpr ((N & 3) == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
+    return d;
+}
+template <int N>
+__device__ __forceinline__ uint32_t pc_dn_lo(uint32_t pm, uint32_t olo) {        // lo: its statistics + the 16-bit increment
+    uint32_t d;
+    if constexpr ((N & 1) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(d) : "v"(pm), "v"(olo));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(d) : "v"(pm), "v"(olo));
+    return d;
+}
+template <int W, int C, int RULE, int ORD>
+struct PcRowS {
+    static constexpr int ND = (W + 3) / 4, NDM = (W + 1) / 2;
+    using T = PcTag<RULE>;
+    template <int N>
+    static __device__ __forceinline__ void reload(uint32_t (&pw)[ND], uint32_t (&pm)[NDM], pc_lds_u32* nxt) {   // column N's operands have been read
+        if constexpr (N >= 0 && N < W && ((N & 1) || N == W - 1)) {
+            if constexpr ((N & 3) == 3 || N == W - 1) pw[N >> 2] = nxt[(N >> 2) * 64];
+            pm[N >> 1] = nxt[(ND + (N >> 1)) * 64];
+            PC_SB();
+        }
+    }
+    // what cell 0 needs before the pipelined sweep starts: its F maximum and column 1's diagonal term
+    static __device__ __forceinline__ void start(double (&Hou)[W], double (&Fu)[W], uint32_t (&pw)[ND], uint32_t (&pm)[NDM], pc_lds_u32* nxt,
+                                                 double& Fm, uint32_t& dnh, uint32_t& dnl) {
+        PC_SB();
+        Fm = pc_max64(Hou[0], Fu[0]); PC_SB();
+        dnh = 0; dnl = 0;
+        if constexpr (W > 1) { dnh = pc_dn_hi<1>(pw[0], pc_hi(Hou[0])); PC_SB(); dnl = pc_dn_lo<1>(pm[0], pc_lo(Hou[0])); PC_SB(); reload<1>(pw, pm, nxt); }
+    }
+    static __device__ __forceinline__ void run(double D, double HoL, double EL, double Fm, uint32_t dnh, uint32_t dnl, double (&Hou)[W], double (&Fu)[W],
+                                               uint32_t (&pw)[ND], uint32_t (&pm)[NDM], pc_lds_u32* nxt, double& E_out) {
+        constexpr bool HAS1 = C + 1 < W, HAS2 = C + 2 < W;
+        if constexpr (T::cyclic) HoL = pc_pack(pc_hi(HoL) + (uint32_t)(T::tOE - T::tOF), pc_lo(HoL));
+        double E, H, Fm2 = 0.0; uint32_t dnh2 = 0, dnl2 = 0;
+        if constexpr (ORD <= 2 || ORD >= 5) {
+            // pc_cell64's order; s_nop 0 at the positions the order number names: P0 ahead of the E maximum (i.e. behind the previous
+            // cell's Ho), P1 ahead of the re-tags, P2 / P3 ahead of the two H maxima, P4 ahead of the Ho fix-up, P5 inside it
+            constexpr bool P0 = ORD == 5 || ORD == 6 || ORD == 7, P1 = ORD == 2 || ORD == 5 || ORD == 6 || ORD == 8, P2 = ORD == 6, P3 = ORD == 6,
+                           P4 = ORD == 2 || (ORD >= 5 && ORD <= 9), P5 = ORD == 6;
+            if constexpr (P0) { asm volatile("s_nop 0"); PC_SB(); }
+            E = pc_max64(HoL, EL); PC_SB();
+            Fm = pc_max64(Hou[C], Fu[C]); PC_SB();
+            if constexpr (HAS1) { dnh = pc_dn_hi<C + 1>(pw[(C + 1) >> 2], pc_hi(Hou[C])); PC_SB(); dnl = pc_dn_lo<C + 1>(pm[(C + 1) >> 1], pc_lo(Hou[C])); PC_SB(); }
+            if constexpr (P1) { asm volatile("s_nop 0"); PC_SB(); }
+            E = pc_retag_from<T::tOE, T::tE>(E); PC_SB();
+            Fm = pc_retag_from<T::tOF, T::tF>(Fm); PC_SB();
+            if constexpr (P2) { asm volatile("s_nop 0"); PC_SB(); }
+            H = pc_max64(D, Fm); PC_SB();
+            if constexpr (P3) { asm volatile("s_nop 0"); PC_SB(); }
+            H = pc_max64(H, E); PC_SB();
+            if constexpr (P4) { if constexpr (ORD == 8) asm volatile("s_nop 1"); else asm volatile("s_nop 0"); PC_SB(); }
+            const uint32_t t = pc_hi(H) & ~3u; PC_SB();
+            if constexpr (P5) { asm volatile("s_nop 0"); PC_SB(); }
+            Hou[C] = pc_pack(t + (uint32_t)(T::tOF - 40), pc_lo(H)); PC_SB();
+            Fu[C] = Fm;
+            reload<C + 1>(pw, pm, nxt);
+        } else {
+            E = pc_max64(HoL, EL); PC_SB();
+            Fm = pc_retag_from<T::tOF, T::tF>(Fm); PC_SB();
+            if constexpr (HAS2) { dnl2 = pc_dn_lo<C + 2>(pm[(C + 2) >> 1], pc_lo(Hou[C + 1])); PC_SB(); }
+            E = pc_retag_from<T::tOE, T::tE>(E); PC_SB();
+            H = pc_max64(D, Fm); PC_SB();
+            if constexpr (HAS1) { Fm2 = pc_max64(Hou[C + 1], Fu[C + 1]); PC_SB(); }
+            H = pc_max64(H, E); PC_SB();
+            if constexpr (HAS2) { dnh2 = pc_dn_hi<C + 2>(pw[(C + 2) >> 2], pc_hi(Hou[C + 1])); PC_SB(); }
+            if constexpr (ORD == 4) { asm volatile("s_nop 0"); PC_SB(); }
+            const uint32_t t = pc_hi(H) & ~3u; PC_SB();
+            Hou[C] = pc_pack(t + (uint32_t)(T::tOF - 40), pc_lo(H)); PC_SB();
+            Fu[C] = Fm;
+            if constexpr (HAS2) reload<C + 2>(pw, pm, nxt);
+        }
+        if constexpr (HAS1) PcRowS<W, C + 1, RULE, ORD>::run(pc_pack(dnh, dnl), Hou[C], E, Fm2, dnh2, dnl2, Hou, Fu, pw, pm, nxt, E_out);
         else E_out = E;
     }
 };
@@ -646,6 +773,10 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
         if constexpr (U8) {
             PcRowU8<W, 0, RULE, PAR>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, u_sc, u_in, u_cur, nxt_addr, o_E);
             u_cur = nxt_addr;
+        } else if constexpr (INC16 && PC_CELL_ORDER > 0) {
+            double Fm = 0.0; uint32_t dnh = 0, dnl = 0;
+            if constexpr (PC_CELL_ORDER == 3 || PC_CELL_ORDER == 4) PcRowS<W, 0, RULE, PC_CELL_ORDER>::start(Hou, Fu, pw, pm, nxt, Fm, dnh, dnl);
+            PcRowS<W, 0, RULE, PC_CELL_ORDER>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Fm, dnh, dnl, Hou, Fu, pw, pm, nxt, o_E);
         } else PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
         asm volatile("" : "+s"(lastm));                                   // test here, not 140 instructions earlier (the compiler would carry the result as a lane mask: one VALU compare)
         if (lastm != 0) {                                                 // a row's last cell left the lane holding column lb-1
