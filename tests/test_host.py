@@ -4,6 +4,8 @@ TSV I/O, the C-ABI export list, and loud failure without the HIP library."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -329,6 +331,24 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
         hip.load()
     with pytest.raises(hip.HipLibraryError):
         hip.Context(0)
+
+
+def test_native_variant_selects_a_library_next_to_the_product_one():
+    """PHAMCLUST_NATIVE_VARIANT=<name> (tools/build_variant.py: A/B of two builds in one GPU call) loads
+    csrc/libphamclust_hip_<name>.so; unset -- or "asan", which names the HOST libraries' sanitized twins -- the product library;
+    a variant that was never built fails loudly instead of falling back."""
+    code = ("import os, sys; sys.path.insert(0, %r); from phamclust_amd import hip; print(os.path.basename(hip.LIB_PATH));\n"
+            "try:\n    hip.load(); print('loaded')\nexcept hip.HipLibraryError: print('refused')") % REPO
+    def run(variant):
+        env = dict(os.environ)
+        env.pop("PHAMCLUST_NATIVE_VARIANT", None)
+        if variant is not None:
+            env["PHAMCLUST_NATIVE_VARIANT"] = variant
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert run(None) == ["libphamclust_hip.so", "loaded"]
+    assert run("asan")[0] == "libphamclust_hip.so"
+    assert run("hooks")[0] == "libphamclust_hip_hooks.so"
+    assert run("no_such_build") == ["libphamclust_hip_no_such_build.so", "refused"]
 
 
 def test_product_never_imports_the_oracle():
