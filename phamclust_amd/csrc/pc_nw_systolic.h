@@ -824,8 +824,9 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
 // lb <= 8,191).
 // ---------------------------------------------------------------------------------
 #define PC_STRIP_WAVES 4                                           // most waves per workgroup = rows per task (one row per wave)
+#define PC_STRIP_WIN 32                                            // stream entries a strip wave stages per refill (the idle half of the wave stages the boundary line: fixed)
 #define PC_STRIP_BND 64                                            // boundary entries a wave keeps staged (two refill windows)
-__host__ __device__ constexpr int pc_strip_wave_lds_dwords() { return 16 + PC_WIN + 4 * PC_STRIP_BND; }
+__host__ __device__ constexpr int pc_strip_wave_lds_dwords() { return 16 + PC_STRIP_WIN + 4 * PC_STRIP_BND; }
 
 // PIPE (r04, second form): the passes of ONE alignment spread over the workgroup's waves.  Wave w takes passes w, w + NWV, ... of the
 // task's rows, one row after the other; each wave builds the profile of its own pass (private LDS), writes its boundary line as
@@ -861,8 +862,8 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
     constexpr uint32_t half_dw = INC16 ? (uint32_t)(((ROWS + 1) / 2) * RS * 64) : 0u;
     auto row_part = [&](uint32_t r) { return (INC16 ? ((r >> 1) * (uint32_t)(RS * 64) + (r & 1u) * 32u) : r * (uint32_t)(RS * 64)) * (BYTE_OFF ? 4u : 1u); };
     uint32_t* wreg = smem + 144 + wv * pc_strip_wave_lds_dwords();
-    uint32_t* ring = wreg + 16;                                    // [PC_WIN] staged stream entries
-    uint32_t* bnd = ring + PC_WIN;                                 // [PC_STRIP_BND][4] staged boundary entries (Ho.hi, Ho.lo, E.hi, E.lo)
+    uint32_t* ring = wreg + 16;                                    // [PC_STRIP_WIN] staged stream entries
+    uint32_t* bnd = ring + PC_STRIP_WIN;                                 // [PC_STRIP_BND][4] staged boundary entries (Ho.hi, Ho.lo, E.hi, E.lo)
     constexpr int PROF_DW = (INC16 ? 2 * ((ROWS + 1) / 2) : ROWS) * RS * 64;     // one profile (PIPE: one per wave)
     uint32_t* prof = smem + 144 + NWV * pc_strip_wave_lds_dwords() + (PIPE ? wv * PROF_DW : 0);
     // PIPE: word 0 of a wave's region = its progress (passes done << 17 | row steps done of the pass it is in)
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
             double o_E = pc_pack((uint32_t)(PC_NEG4 + TG::tE), 0u);
             double p_HoL = pc_pack((uint32_t)(PC_NEG4 + TG::tOF), 0u);
             uint32_t v_hb = (uint32_t)(PC_S4(-22) + TG::tOF), v_h00 = (uint32_t)(PC_S4(-12) + TG::tOF);
-            const int hl = lane & (PC_WIN - 1);
+            const int hl = lane & (PC_STRIP_WIN - 1);
             auto refill = [&](int base) {
                 if constexpr (PIPE) {
                     // `base - 2` steps of this pass are done: their boundary entries first, then the word that says so
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
                 }
                 pc_wave_lds_sync();
                 const uint32_t p = (uint32_t)base + (uint32_t)hl;
-                if (lane < PC_WIN) {                                // the stream entries of positions base .. base + 31
+                if (lane < PC_STRIP_WIN) {                                // the stream entries of positions base .. base + 31
                     uint32_t entry = 0;
                     if (p < (uint32_t)seg_len) {
                         const int i = (int)p - 1;
@@ -1026,7 +1027,7 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
             const unsigned long long headm = __builtin_amdgcn_ballot_w64(is_head), outm = __builtin_amdgcn_ballot_w64(is_out), headoutm = headm | outm;
             const uint32_t v_base_step = PC_BASE_STEP;
             auto step = [&](int t, const bool even, uint32_t a, uint32_t& a_nxt) {
-                if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
+                if (even && ((t + 2) & (PC_STRIP_WIN - 1)) == 0) refill(t + 2);
                 // the head lane's left-hand boundary of this row: the constants of column -1 in the first pass, else what the
                 // previous pass left for stream position t (every lane reads the one entry: a broadcast)
                 uint32_t bHh = v_hb, bHl = 0u, bEh = v_nege, bEl = 0u;
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
                 }
                 pc_lds_u32* nxt = (pc_lds_u32*)(size_t)row_addr(a_nxt);
                 if (even) {
-                    const uint2 e2 = *(const uint2*)&ring[(t + 2) & (PC_WIN - 1)];
+                    const uint2 e2 = *(const uint2*)&ring[(t + 2) & (PC_STRIP_WIN - 1)];
                     e_nxt = e2.x; e_b = e2.y;
                 } else e_nxt = e_b;
                 unsigned long long rstm = 0, lastm = 0;
