@@ -83,6 +83,13 @@ def dist_mode():
 ALIGNED_METRICS = ("aai", "peq", "aai_ppos")
 
 
+def force_exchange():
+    """PHAMCLUST_DIST_FORCE_EXCHANGE=1: run the exchange step (gather / reduce) and the root's assembly even in a ONE-rank
+    group.  A box with one GPU cannot host two RCCL ranks; this is how the `nccl` branches below -- the exact calls an
+    8-GPU job makes -- execute on such a box (tests/test_gpu_parity.py::test_rccl_branches_with_one_rank)."""
+    return os.environ.get("PHAMCLUST_DIST_FORCE_EXCHANGE") == "1"
+
+
 def uses_alignment_slices(metric, mode=None):
     """True when a multi-rank fill of ``metric`` goes down the alignment-sliced route (one helper for fill_distributed and
     for bench.py's bookkeeping: every rank of that route reports the WHOLE job's counts, not its share)."""
@@ -144,9 +151,10 @@ def fill_distributed_alignments(ctx, metric, as_distance=True, group=None):
     stats["ms_plan"] = plan["ms_plan"]
     stats["ms_total"] = plan["ms_plan"] + stats["ms_align"]             # what THIS rank spent on the device (root: + ms_root_reduce)
     stats["dist_mode"] = "alignments"
-    gloo = world > 1 and dist.get_backend(group) == "gloo"
+    exchange = world > 1 or force_exchange()
+    gloo = exchange and dist.get_backend(group) == "gloo"
     clock = _StageClock(device, on_device=not gloo)
-    if world > 1:
+    if exchange:
         with clock("ms_exchange"):
             if gloo:                                                      # rehearsal transport: staged through host memory
                 host = res.cpu()
@@ -188,9 +196,10 @@ def fill_distributed(ctx, metric, as_distance=True, group=None, balanced=True, m
     stats = ctx.fill_shard_dev(metric, as_distance, shard.data_ptr(), stream)
     stats["dist_mode"] = "pairs"
     stats["shard_pairs"] = ctx.shard_pairs()
-    gloo = world > 1 and dist.get_backend(group) == "gloo"
+    exchange = world > 1 or force_exchange()
+    gloo = exchange and dist.get_backend(group) == "gloo"
     clock = _StageClock(device, on_device=not gloo)
-    if world == 1:
+    if not exchange:
         gathered = shard
     else:
         with clock("ms_exchange"):

@@ -1055,6 +1055,53 @@ def test_bench_two_gpus_rccl(native_built, mode):
     assert "REHEARSAL" not in d["config"]["parallelism"] and d["stage_ms"]["exchange_rank0"] > 0
 
 
+def test_rccl_branches_with_one_rank(native_built):
+    """The `nccl` (= RCCL) branches of the multi-GPU fill on a ONE-GPU box: a one-rank nccl process group and
+    PHAMCLUST_DIST_FORCE_EXCHANGE=1, so that shard -> dist.gather into chunk views of one device buffer -> device assembly
+    (pairs) and plan -> slice -> dist.reduce -> matrix on the root (alignments) run the very calls an 8-GPU job makes, on
+    device tensors, through RCCL.  Every metric must equal the plain fill bit for bit.  (Two ranks cannot share a GPU
+    under RCCL; the two-GPU test below needs a bigger box.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from phamclust_amd import hip
+from phamclust_amd.distributed import fill_distributed
+from phamclust_amd.synth import synth_packed
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+packed = synth_packed(257, 3000, seed=5)
+with hip.Context(0) as ctx:
+    ctx.upload(packed)
+    for metric in ("jc", "af", "aai", "peq"):
+        want = np.array(ctx.fill(metric, True), copy=True)
+        for mode in ("pairs", "alignments"):
+            out, st = fill_distributed(ctx, metric, True, mode=mode)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert st["ms_exchange"] >= 0 and st["exchange_bytes"] > 0, st
+            assert np.array_equal(got, want), (metric, mode)
+            print(metric, mode, st["dist_mode"], "exchange ms", round(st["ms_exchange"], 3), flush=True)
+        ctx.set_shard(0, 1)
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+""" % REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PHAMCLUST_DIST_FORCE_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0 and proc.stdout.strip().endswith("ok"), (proc.stdout[-1500:], proc.stderr[-3000:])
+
+
 def test_graft_entry_smoke(native_built):
     """The driver's smoke(): all six metrics on a small synthetic set against the oracle."""
     import importlib
