@@ -164,6 +164,9 @@ def main():
             sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (WORLD_SIZE={world})")
         a.gpus = world
 
+    # PC_BENCH_FORCE_DIST=1: the whole N > 1 flow -- process group, sharded fill, exchange, assembly, the all_reduce bookkeeping of
+    # this file -- with ONE rank, so that it runs through RCCL on a one-GPU box (two ranks cannot share a GPU under RCCL)
+    multi = world > 1 or os.environ.get("PC_BENCH_FORCE_DIST") == "1"
     import torch
     import torch.distributed as dist
     from phamclust_amd import build, hip
@@ -177,7 +180,10 @@ def main():
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi and world == 1:                               # the N > 1 flow with ONE rank (see `multi` above)
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ["PHAMCLUST_DIST_FORCE_EXCHANGE"] = "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -186,7 +192,7 @@ def main():
             dist.init_process_group(backend)
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         build.build_all()                 # no-op when the in-tree libraries are current; one rank only
-    if world > 1:
+    if multi:
         dist.barrier()
     # What a rank costs before it can fill anything (never part of `value`): this process's own start -- interpreter, torch
     # import, process-group init -- up to the first barrier all ranks pass.  Max over ranks below.  (The launcher's own
@@ -199,10 +205,10 @@ def main():
     needs_residues = a.metric in ("aai", "peq")
     ctx.upload(packed, residues=needs_residues)            # gcs / jc / pocp / af never read a residue: part 1 of the upload only
     n_pairs = packed.n_pairs
-    sliced = world > 1 and uses_alignment_slices(a.metric)                               # PHAMCLUST_DIST_MODE=alignments
+    sliced = multi and uses_alignment_slices(a.metric)                               # PHAMCLUST_DIST_MODE=alignments
 
     def step():
-        if world == 1:
+        if not multi:
             out = torch.empty(max(n_pairs, 1), dtype=torch.float64, device="cuda")
             st = ctx.fill_dev(a.metric, True, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
             return out[:n_pairs], st
@@ -210,7 +216,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -225,7 +231,7 @@ def main():
         stats.append(st)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -248,13 +254,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         upload_s = float(t.item())
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
     ms_step = elapsed / a.steps * 1e3
     value = n_pairs * a.steps / elapsed
-    if world == 1:
+    if not multi:
         n_aln = stats[-1]["n_alignments"]; n_cells = stats[-1]["n_cells"]; n_rbytes = stats[-1]["n_residue_bytes"]
         n_daln = stats[-1]["n_distinct_alignments"]; n_dcells = stats[-1]["n_distinct_cells"]
         ms_align = sum(s["ms_align"] for s in stats) / len(stats)
@@ -291,12 +297,13 @@ def main():
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill; `value` = fills with the genomes resident in "
                                f"HBM and the matrix left in HBM (upload and D2H excluded: see value_wall)",
-                   "dist_mode": (dist_mode() if a.metric in ("aai", "peq") else "pairs") if world > 1 else None,
+                   "dist_mode": (dist_mode() if a.metric in ("aai", "peq") else "pairs") if multi else None,
                    "n_genomes": a.genomes, "n_phams": packed.n_phams, "metric_selector": a.metric, "genome_pairs": n_pairs,
                    "n_genes": packed.n_genes, "n_residues": int(packed.residues.size),
                    "parallelism": (f"alignments sliced over {world} GPUs (every rank plans the whole fill) + 1 RCCL reduce of their results + matrix on rank 0"
-                                   if sliced else f"static pair shard over {world} GPU(s)" + (" + 1 RCCL gather + device assembly" if world > 1 else ""))
-                                  + ("" if backend == "nccl" or world == 1 else f" [REHEARSAL: backend {backend}, ranks share GPUs]")},
+                                   if sliced else f"static pair shard over {world} GPU(s)" + (" + 1 RCCL gather + device assembly" if multi else ""))
+                                  + ("" if backend == "nccl" or world == 1 else f" [REHEARSAL: backend {backend}, ranks share GPUs]")
+                                  + (" [REHEARSAL: ONE rank, exchange forced (PC_BENCH_FORCE_DIST)]" if multi and world == 1 else "")},
     }
     if a.metric in ("aai", "peq"):
         # this rank-set's K4 launches of one fill; multi-GPU: work of all ranks / slowest rank's time
@@ -354,7 +361,7 @@ def main():
                             "frac": nb / t / 1e9 / 8000.0 if t > 0 else 0.0, "traffic": None,
                             "kernel": "k_set_popc / k_walk", "algorithmic_bytes_per_fill": nb, "ms_kernels_per_fill": ms_dev}
     line["device_ms_per_fill"] = ms_dev
-    if world == 1:
+    if not multi:
         line["stage_ms"] = {k: sum(s[k] for s in stats) / len(stats) for k in ("ms_plan", "ms_align", "ms_reduce")}
         line["n_chunks"] = stats[-1]["n_chunks"]
     else:
@@ -405,7 +412,7 @@ def main():
     valid = bool(line.get("verified", {}).get("bit_exact", True))
     line["valid"] = valid
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     if not valid:
         sys.exit(1)

@@ -1102,6 +1102,33 @@ print("ok")
     assert proc.returncode == 0 and proc.stdout.strip().endswith("ok"), (proc.stdout[-1500:], proc.stderr[-3000:])
 
 
+@pytest.mark.parametrize("mode", ["pairs", "alignments"])
+def test_bench_distributed_flow_with_one_rank_over_rccl(native_built, mode):
+    """bench.py's N > 1 flow -- nccl process group, sharded fill, exchange, assembly, its all_reduce bookkeeping, the init_s /
+    upload_s keys -- with ONE rank (PC_BENCH_FORCE_DIST=1): everything the driver's 8-GPU run executes except a second GPU."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PC_BENCH_FORCE_DIST="1", PHAMCLUST_DIST_MODE=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("PC_BENCH_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--genomes", "301", "--steps", "2", "--warmup", "1",
+                           "--verify-pairs", "3000", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["verified"]["bit_exact"] is True and d["config"]["dist_mode"] == mode
+    assert "ONE rank" in d["config"]["parallelism"] and d["stage_ms"]["exchange_rank0"] > 0 and d["stage_ms"]["assemble_rank0"] > 0
+    assert d["init_s"] > 0 and d["upload_s"] > 0 and d["value_wall_incl_init"] > 0
+    assert "HIP events" in d["stage_ms"]["clock"]
+
+
 def test_graft_entry_smoke(native_built):
     """The driver's smoke(): all six metrics on a small synthetic set against the oracle."""
     import importlib
