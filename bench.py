@@ -311,25 +311,29 @@ def main():
         per_gpu_time = ms_align / 1e3
         hbm_achieved = algo_bytes / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
         gcups = n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
-        # The bound that binds: VALU issue.  256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: a wave64 VALU instruction holds its SIMD for
-        # 4 clocks in ANY mixed stream -- unmixed runs of plain VOP2 add / sub / and / or go at 2 (tests/hw/valu_rate.hip ->
-        # profiles/valu_issue_rate.json), but a block of ten costs 40 clocks whatever share of them it holds, in whatever order
-        # (tests/hw/valu_mix.hip -> profiles/r04/experiments/valu_mix_probe.txt: 8 cheap + 2 dear, the cell's own order, one run
-        # of four, isolated ones: 39.5-40.8 at 4 and 8 waves per SIMD).  The cell is 10 instructions: four v_max_f64 acting as
-        # lexicographic (score, tie-break tag, path statistics) maxima, two SDWA adds from the profile, four tag / open-penalty
-        # fix-ups (r01's cell was 15; launch classes with long column genes run an 11-instruction cell that compares residues
-        # instead of reading a second profile, and every row step adds a ~9-instruction prologue -- the ceiling is not lowered
-        # for either).  r04: the two re-tags as v_or_b32 instead of v_and_or_b32 took 6 % off the fill at the same instruction
-        # count (the VOP3 form behind a v_max_f64 result cost more than its issue slot), frac 0.856 -> 0.916.
+        # The bound that binds: VALU issue, priced per instruction class.  A SIMD retires a wave64 VALU instruction in 4 clocks
+        # (16 lanes/clk) for v_max_f64, SDWA / DPP / VOP3 forms, compares and v_addc, and in 2 (32 lanes/clk) for the plain VOP2
+        # add / sub / and / or once several waves share it (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json: 4.15 and
+        # 2.15 in unmixed streams).  The cell is 10 instructions: four v_max_f64 acting as lexicographic (score, tie-break tag, path
+        # statistics) maxima and two SDWA adds from the profile (4 clocks each), four tag / open-penalty fix-ups -- v_or, v_or,
+        # v_and, v_sub (2 each): 32 issue clocks per 64 cells, 4,915 GCUPS.  r01-r03 priced all ten at 4 clocks (3,932 GCUPS): a
+        # probe of identical waves running a mixed stream in lockstep measures 4.0 per instruction whatever the mix
+        # (tests/hw/valu_mix.hip).  The kernel itself refutes that ceiling: its counters show 11.49 executed VALU instructions per
+        # cell (the 11-instruction compare cell of long column genes, step prologues, idle lanes), and 11.49 x 64-lane
+        # instructions at this line's rate are 3.8 clocks per instruction per SIMD -- below 4 -- so its waves, which are not in
+        # lockstep, do get the cheap class cheaper; and turning two VOP3 re-tags into VOP2 ones (r04) took 6 % off the fill at the
+        # same instruction count.  `frac_at_4_clk_per_instruction` is the r03 figure's successor, for continuity only.
         instr_per_cell = 10
-        lane_ops_peak = 256 * 4 * 16 * 2.4e9
-        lane_ops = instr_per_cell * gcups * 1e9
+        issue_clk_per_cell = 6 * 4 + 4 * 2
+        peak_gcups = 256 * 4 * 64 * 2.4e9 / issue_clk_per_cell / 1e9
         line["roofline"] = {
-            "bound": "valu", "achieved": lane_ops / 1e12, "peak": lane_ops_peak / 1e12, "unit": "Tlane-op/s (VALU)",
-            "frac": lane_ops / lane_ops_peak, "traffic": None,
+            "bound": "valu", "achieved": gcups / 1e3, "peak": peak_gcups / 1e3, "unit": "TCUPS (DP cells/s; VALU issue clocks per cell priced per instruction class)",
+            "frac": gcups / peak_gcups, "traffic": None,
             "kernel": "k_nw_systolic_tier<TIER,RULE,cell> / k_nw_systolic<W,RULE> (all launches of one fill, per GPU)",
-            "instr_per_cell": instr_per_cell, "peak_gcups": lane_ops_peak / instr_per_cell / 1e9, "achieved_gcups": gcups,
-            "issue_rate_source": "profiles/valu_issue_rate.json (4.0-4.15 clk per wave64 instruction per SIMD for every class in the cell, v_max_f64 included) and profiles/r04/experiments/valu_mix_probe.txt (mixed blocks: 4.0 per instruction)",
+            "instr_per_cell": instr_per_cell, "issue_clk_per_cell": issue_clk_per_cell, "peak_gcups": peak_gcups, "achieved_gcups": gcups,
+            "frac_at_4_clk_per_instruction": gcups / (256 * 4 * 16 * 2.4e9 / instr_per_cell / 1e9),
+            "issue_rate_source": "profiles/valu_issue_rate.json (unmixed: 4.15 / 2.15 clk), profiles/r04/final/counters.json (11.49 executed VALU instructions per cell), "
+                                 "profiles/r04/experiments/retag_one_op_ab.txt, valu_mix_probe.txt",
             "ms_kernels_per_fill": ms_align, "n_alignments": n_aln, "dp_cells": n_cells,
             # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
             "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells, "gcups_per_gpu": gcups,
