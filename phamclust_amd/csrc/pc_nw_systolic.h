@@ -283,6 +283,7 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
 // 2: 118.7 | 3: 122.8 | 4: 119.2 | 5: 119.6 | 6: 121.7 | 7: 119.8 | 8: 118.3 | 9: 120.7.  The ORDER is worth nothing (1 = 3, 2 = 4): what
 // the asm blocks owe their 4.5 % to is the compiler's two s_nop 0 -- a pause of the WAVE ahead of a 32-bit instruction that reads a
 // v_max_f64 result (an independent VALU instruction in the same place does not do it: 3), and more pauses only cost (5, 6, 7).
+// Longer pauses ahead of the cheap runs (10 / 11 / 12: s_nop 1 / 3 / 7) only cost: 122.0 / 124.9 / 137.8.
 // So the product stays on pc_cell64's asm blocks; this harness is compiled out.
 #ifndef PC_CELL_ORDER
 #define PC_CELL_ORDER 0
@@ -332,20 +333,23 @@ struct PcRowS {
         if constexpr (ORD <= 2 || ORD >= 5) {
             // pc_cell64's order; s_nop 0 at the positions the order number names: P0 ahead of the E maximum (i.e. behind the previous
             // cell's Ho), P1 ahead of the re-tags, P2 / P3 ahead of the two H maxima, P4 ahead of the Ho fix-up, P5 inside it
-            constexpr bool P0 = ORD == 5 || ORD == 6 || ORD == 7, P1 = ORD == 2 || ORD == 5 || ORD == 6 || ORD == 8, P2 = ORD == 6, P3 = ORD == 6,
-                           P4 = ORD == 2 || (ORD >= 5 && ORD <= 9), P5 = ORD == 6;
+            constexpr bool P0 = ORD == 5 || ORD == 6 || ORD == 7, P1 = ORD == 2 || ORD == 5 || ORD == 6 || ORD == 8 || ORD >= 10, P2 = ORD == 6, P3 = ORD == 6,
+                           P4 = ORD == 2 || ORD >= 5, P5 = ORD == 6;
+            // 10 / 11 / 12: longer pauses ahead of the two runs of cheap instructions (s_nop 1 / 3 / 7 at P1 and P4): a cheap instruction
+            // rides the second VALU pipe only beside another wave's (valu2_share.txt) -- does waiting longer find it a partner?
+#define PC_PAUSE_LONG() do { if constexpr (ORD == 10) asm volatile("s_nop 1"); else if constexpr (ORD == 11) asm volatile("s_nop 3"); else asm volatile("s_nop 7"); } while (0)
             if constexpr (P0) { asm volatile("s_nop 0"); PC_SB(); }
             E = pc_max64(HoL, EL); PC_SB();
             Fm = pc_max64(Hou[C], Fu[C]); PC_SB();
             if constexpr (HAS1) { dnh = pc_dn_hi<C + 1>(pw[(C + 1) >> 2], pc_hi(Hou[C])); PC_SB(); dnl = pc_dn_lo<C + 1>(pm[(C + 1) >> 1], pc_lo(Hou[C])); PC_SB(); }
-            if constexpr (P1) { asm volatile("s_nop 0"); PC_SB(); }
+            if constexpr (P1) { if constexpr (ORD >= 10) PC_PAUSE_LONG(); else asm volatile("s_nop 0"); PC_SB(); }
             E = pc_retag_from<T::tOE, T::tE>(E); PC_SB();
             Fm = pc_retag_from<T::tOF, T::tF>(Fm); PC_SB();
             if constexpr (P2) { asm volatile("s_nop 0"); PC_SB(); }
             H = pc_max64(D, Fm); PC_SB();
             if constexpr (P3) { asm volatile("s_nop 0"); PC_SB(); }
             H = pc_max64(H, E); PC_SB();
-            if constexpr (P4) { if constexpr (ORD == 8) asm volatile("s_nop 1"); else asm volatile("s_nop 0"); PC_SB(); }
+            if constexpr (P4) { if constexpr (ORD >= 10) PC_PAUSE_LONG(); else if constexpr (ORD == 8) asm volatile("s_nop 1"); else asm volatile("s_nop 0"); PC_SB(); }
             const uint32_t t = pc_hi(H) & ~3u; PC_SB();
             if constexpr (P5) { asm volatile("s_nop 0"); PC_SB(); }
             Hou[C] = pc_pack(t + (uint32_t)(T::tOF - 40), pc_lo(H)); PC_SB();
