@@ -666,6 +666,16 @@ int pc_launch_sparse(int mode, const PcDev& d, const PcShard& sh, double* out, i
 #define S6_GCS PCW_SPARSE_GCS                                     // MODE values beside PCW_POCP / PCW_AF: shared-pham counts only (gcs, jc)
 #define S6_JC PCW_SPARSE_JC
 #define S6_SUPER 16                                               // super-tile edge in tiles: 2 x 1,024 rows' entry lists = 1.6 MB of an XCD's 4-MB L2
+// af: a probe step with at least this many broadcast entries takes them through LDS instead of the readlane loop (below).  Measured
+// (profiles/r04/experiments/dense_broadcast_af.txt; af at N = 2,000): threshold 4: 0.120 ms, 8: 0.098, 12: 0.0905, 24: 0.0894; never: 0.127
+#ifndef S6_DENSE_MIN
+#define S6_DENSE_MIN 24
+#endif
+#define S6_STAGE_DWORDS 192                                       // per wave: 64 x (mask low, mask high, value)
+// Which instances take it: af's two-batch one (small and medium collections, 128 registers).  The one-batch instances sit at 78-79 of
+// the 80 registers six waves per SIMD leave and spilled 8-12 dwords with it (scratch stores reach HBM); pocp's two-batch instance
+// spilled 24; the counting mode keeps its four workgroups per CU -- no LDS to spare.
+__host__ __device__ constexpr bool pc_s6_dense(int mode, int batches) { return S6_DENSE_MIN > 0 && mode == PCW_AF && batches == 2; }
 // S6_B: 64-entry batches of a row held in registers -- 2 when one mask chunk holds all phams (a row's ~100 entries), 1 when the
 // phams take several chunks (a row then has a few dozen entries per chunk; half the loads and probe steps, and registers for a
 // third workgroup per CU: the launch bound asks for six waves per SIMD there)
@@ -684,6 +694,7 @@ __global__ __launch_bounds__(64 * S6_WAVES, pc_s6_waves_per_simd(MODE, S6_B)) vo
     __shared__ int g_s[S6_T], g_t[S6_T];                                           // genome of tile row r, -1: none
     __shared__ long long tot_s[S6_T], tot_t[S6_T];                                 // its total (genes, resp. residues): the epilogue's denominators
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t* stage = acc + S6_T * S6_LD + wave * S6_STAGE_DWORDS;                 // af / pocp: this wave's broadcast entries (pc_s6_dense)
     constexpr bool COUNT = MODE >= S6_GCS;                                          // gcs / jc: |S n T| only -- every hit adds 1, and ONE direction does it
     const uint2* __restrict__ ent = MODE == PCW_POCP ? d.sp_cnt : d.sp_len;                   // (dense pham id, value): phams with at least two holders
     // Unit n of the XCD-aware tile order goes to workgroup n mod gridDim (a multiple of 8, so a workgroup keeps to the tiles of
@@ -759,6 +770,26 @@ __global__ __launch_bounds__(64 * S6_WAVES, pc_s6_waves_per_simd(MODE, S6_B)) vo
                 if (pc == 2) atomicAdd(&acc[decltype(to_row)::value ? r * S6_LD + o2 : o2 * S6_LD + r], v);
             }
             unsigned long long heavy = __ballot(pc > 2);                            // many hits: the wave adds them, lanes = rows of the other side
+            if constexpr (pc_s6_dense(MODE, S6_B)) {
+                // Inside a cluster nearly every entry is such a hit (a pair shares ~85 phams), and the loop below takes ~10 instructions
+                // and a VALU -> SGPR -> EXEC round trip per entry: the launch lasted as long as its slowest in-cluster tile.  Dense
+                // form (r04): the 64 entries go to LDS (mask halves and value; zero where the lane's entry is not a broadcast one), and
+                // lane l walks all 64 -- its own half of the mask by a broadcast read -- adding the value where its bit is set: two LDS
+                // reads and two VALU instructions per entry, no scalar dependency, iterations independent.
+                if (__popcll(heavy) >= S6_DENSE_MIN) {
+                    const bool big = pc > 2;
+                    stage[lane] = big ? m.x : 0u; stage[64 + lane] = big ? m.y : 0u; stage[128 + lane] = v;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the wave's own LDS writes -> its reads (in-order LDS queue)
+                    uint32_t l2 = (uint32_t)lane;
+                    asm volatile("" : "+v"(l2));                                    // (derived per step: hoisted out of the unrolled rows, `mine` and `sh` cost the one-batch instances 8-12 dwords of scratch)
+                    const uint32_t* mine = stage + (l2 & 32u) * 2u;                 // lanes 0-31: low halves, 32-63: high halves
+                    const uint32_t sh = l2 & 31u;
+#pragma unroll 8
+                    for (int k = 0; k < 64; ++k) hs += ((mine[k] >> sh) & 1u) * stage[128 + k];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // reads done before the next step rewrites the stage
+                    heavy = 0;
+                }
+            }
             while (heavy) {
                 const int k = __builtin_ctzll(heavy);
                 asm("s_bitset0_b64 %0, %1" : "+s"(heavy) : "s"(k));
@@ -896,14 +927,15 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
     // ... except that 2,048 ... 7,680 phams are split in two from ~4,000 genomes: the one-batch instances need 59 (gcs / jc), 78 (af) and --
     // held there by the launch bound, 4 dwords of scratch -- 80 (pocp) registers, and with 20 KB of masks three workgroups fit a CU instead
     // of two (N = 20,000, 5,056 phams: jc 2.06 -> 1.79 ms, af 2.89 -> 2.60, pocp 2.61 -> 2.42; below: af at N = 3,000 0.150 ms whole, 0.165 split)
-    int n_chunks = (P64 + 7679) / 7680;
+    const int chunk_cap = pc_s6_dense(mode, 2) ? 6912 : 7680;                       // (6 KB of broadcast staging beside the accumulators)
+    int n_chunks = (P64 + chunk_cap - 1) / chunk_cap;
     if (n_chunks == 1 && P64 >= 2048 && (int64_t)d.N * sh.nown >= (int64_t)4000 * 4000) n_chunks = 2;
     if (const char* force = getenv("PC_S64_CHUNKS")) {                              // test knob (read per launch): at least this many chunks, so that
         const int want_chunks = atoi(force);                                        // small collections reach the one-batch instances and the forced split
         if (want_chunks > n_chunks && want_chunks <= P64 / 64) n_chunks = want_chunks;
     }
     const int CH = (P64 / 64 + n_chunks - 1) / n_chunks * 64;                       // equal chunks (synth(20000,20000): 5 x 4,096: jc 2.67 ms, 3 x 6,720: 2.5)
-    const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4;
+    const size_t lds = (size_t)CH * 8 + (size_t)S6_T * S6_LD * 4 + (pc_s6_dense(mode, CH < P64 ? 1 : 2) ? (size_t)S6_WAVES * S6_STAGE_DWORDS * 4 : 0);
     const unsigned n_units = pc_tile_grid((d.N + S6_T - 1) / S6_T, (sh.nown + S6_T - 1) / S6_T, S6_SUPER);
     const unsigned resident = (unsigned)(2 * (d.n_cu > 0 ? d.n_cu : 256) + 7) / 8u * 8u;      // (the context's own device: pc_ctx_create asked it)
     // three units per workgroup (see the kernel); small matrices: one unit each, up to four times the workgroups that fit the chip
