@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- the headline measurement: genome-pairs/sec of the N x N matrix fill.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          any N: for N > 1 outside a launcher this process starts
+                                                           `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+                                                           CHILD before it has made a GPU call, and relays rank 0's line and the
+                                                           child's exit status (it never re-executes itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...       the same ranks, launched by the caller
+    python bench.py --gpus N --route process               ONE process drives the N GPUs (pc_multi_*: a host thread per device inside the
+                                                           library, the shard exchange as peer copies) -- the same shard and assembly,
+                                                           so the peer-copy exchange can be compared with the RCCL gather on one node
 
 One "step" = one full matrix fill (BASELINE.json metric: genome-pairs/sec, peq) of the
 workload synth(5000, 5000) -m peq -- the configuration the target is quoted on -- with the
@@ -55,7 +61,45 @@ def parse():
     ap.add_argument("--metric", default="peq", choices=["gcs", "jc", "pocp", "af", "aai", "peq"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU-baseline work; 0 disables")
     ap.add_argument("--verify-pairs", type=int, default=20000, help="check this many random pairs against the oracle")
+    ap.add_argument("--route", default="rank", choices=["rank", "process"],
+                    help="N > 1: 'rank' = one process per GPU, one RCCL gather (the measured contract); 'process' = this process drives "
+                         "all N GPUs through pc_multi_* (peer copies)")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: run the N ranks as a CHILD `torch.distributed.run`, relay rank 0's JSON line
+    (with `launched_by` added) and the child's exit status.  Nothing here may touch the GPU -- this process never imports torch,
+    never loads libphamclust_hip and never builds: the ranks own the devices (a process that has initialised HIP must not exec,
+    and has no business holding a context next to the ranks' on device 0)."""
+    import subprocess
+    from phamclust_amd.distributed import free_port              # numpy only
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PC_BENCH_PARENT_T0"] = repr(time.time())
+    touched = sorted(m for m in ("torch", "phamclust_amd.hip") if m in sys.modules)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for text in child.stdout:                                     # rank 0's one JSON line; anything else a rank printed goes to stderr
+        try:
+            obj = json.loads(text)
+            if isinstance(obj, dict) and "metric" in obj:
+                line = obj
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(text)
+    rc = child.wait()
+    if line is not None:
+        line["launched_by"] = {"how": "bench.py parent -> child `python -m torch.distributed.run` (no GPU call, no torch import in the parent)",
+                               "parent_modules_touching_gpu": touched, "child_exit_status": rc}
+        print(json.dumps(line), flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a result line\n")
+        rc = 1
+    return rc
 
 
 def cpu_quota():
@@ -154,15 +198,191 @@ def kernel_source_hash():
     return hashlib.sha256(blob).hexdigest()[:16]
 
 
+def verify_sample(packed, metric, n_verify, fetch):
+    """Sampled check of the assembled matrix against the oracle (random pairs over the whole triangle); ``fetch(condensed
+    indices) -> values`` reads them from wherever the matrix is."""
+    from oracle import oracle as O
+    import numpy as np
+    from phamclust_amd.metrics import parity_note
+    rng = np.random.default_rng(12345)
+    n = packed.n_genomes
+    s_idx = rng.integers(0, n - 1, n_verify)
+    t_idx = rng.integers(0, n, n_verify)
+    lo, hi = np.minimum(s_idx, t_idx), np.maximum(s_idx, t_idx)
+    keep = lo < hi
+    lo, hi = lo[keep], hi[keep]
+    cond = lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)
+    got = np.asarray(fetch(cond))
+    want = O.pairs(packed, metric, lo, hi, as_distance=True)
+    return {"pairs": int(lo.size), "how": "random pairs of the full matrix vs oracle/pc_oracle.c",
+            "max_abs_diff": float(np.max(np.abs(got - want))), "bit_exact": bool(np.array_equal(got, want)),
+            "parity": parity_note(metric)}
+
+
+def child_probe(a, rank, world):
+    """PC_BENCH_CHILD_PROBE=1 (tests/test_distributed_cpu.py): what a rank does BEFORE its first GPU call -- join the group the
+    parent's launcher set up -- and nothing after: rank 0 prints a line that says how many ranks met.  Runs where there is no GPU."""
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("PC_BENCH_BACKEND", "gloo"))
+    box = [None] * world
+    dist.all_gather_object(box, {"rank": rank, "pid": os.getpid(), "argv": sys.argv[1:]})
+    if rank == 0:
+        print(json.dumps({"metric": "genome-pairs/sec", "value": None, "probe": True, "n_gpus": a.gpus, "ranks_seen": dist.get_world_size(),
+                          "ranks": box, "parent_t0": os.environ.get("PC_BENCH_PARENT_T0")}), flush=True)
+    dist.destroy_process_group()
+    if os.environ.get("PC_BENCH_CHILD_PROBE_FAIL") == str(rank):
+        sys.exit(7)
+
+
+def main_one_process(a):
+    """--route process: this process drives the N GPUs (hip.MultiContext = pc_multi_*).  One step = upload-free fill of the whole
+    matrix DELIVERED to page-locked host memory (the call's contract: shard fills on every device, peer copies into the root's
+    gather buffer, assembly, D2H) -- so `value` here contains the D2H the rank route's `value` leaves out; `value_resident_estimate`
+    takes it off again.  PC_BENCH_DEVICE_IDS=0,0 names the devices (an id may repeat: rehearsal on a one-GPU box)."""
+    from phamclust_amd import build, hip
+    from phamclust_amd.synth import synth_packed
+    build.build_all()
+    ids = [int(x) for x in os.environ["PC_BENCH_DEVICE_IDS"].split(",")] if os.environ.get("PC_BENCH_DEVICE_IDS") else list(range(a.gpus))
+    if len(ids) != a.gpus:
+        sys.exit(f"PC_BENCH_DEVICE_IDS names {len(ids)} devices, --gpus {a.gpus}")
+    packed = synth_packed(a.genomes, a.phams)
+    n_pairs = packed.n_pairs
+    needs_residues = a.metric in ("aai", "peq")
+    t0 = time.perf_counter()
+    mc = hip.MultiContext(ids)
+    t_create = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mc.upload(packed, residues=needs_residues)
+    upload_s = time.perf_counter() - t0
+    out, st = None, None
+    for _ in range(a.warmup):
+        out, st = mc.fill(a.metric, True, want_stats=True, borrow=True)
+    stats = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out, st = mc.fill(a.metric, True, want_stats=True, borrow=True)        # synchronous: returns with the matrix on the host
+        stats.append(st)
+    elapsed = time.perf_counter() - t0
+    world = len(ids)
+    per = [s["per_device"] for s in stats]
+    mean = lambda f: sum(f(s) for s in stats) / len(stats)                       # noqa: E731
+    ms_align_max = mean(lambda s: max(p["ms_align"] for p in s["per_device"]))
+    ms_align_min = mean(lambda s: min(p["ms_align"] for p in s["per_device"]))
+    last = per[-1]
+    tot = lambda key: sum(p[key] for p in last)                                # noqa: E731
+    distinct_same_gpu = len(set(ids)) < len(ids)
+    line = {
+        "metric": "genome-pairs/sec", "value": n_pairs * a.steps / elapsed, "unit": "genome-pairs/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic", "route": "process", "ranks_seen": 1, "device_ids": ids,
+        "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill from ONE process over {world} device(s); "
+                               f"`value` = fills with the genomes resident in HBM, the matrix DELIVERED to page-locked host memory (D2H included)",
+                   "n_genomes": a.genomes, "n_phams": packed.n_phams, "metric_selector": a.metric, "genome_pairs": n_pairs,
+                   "n_genes": packed.n_genes, "n_residues": int(packed.residues.size),
+                   "parallelism": f"static cost-balanced pair shard over {world} device(s) driven by one process (pc_multi_*) + peer copies into the "
+                                  f"root's gather buffer + device assembly" + (" [REHEARSAL: contexts share a GPU]" if distinct_same_gpu else "")},
+        "stage_ms": {"align_max_over_devices": ms_align_max, "align_min_over_devices": ms_align_min,
+                     "plan_max_over_devices": mean(lambda s: max(p["ms_plan"] for p in s["per_device"])),
+                     "device_total_max_over_devices": mean(lambda s: s["ms_total"]),
+                     "exchange_slowest_copy": mean(lambda s: s["ms_exchange"]), "assemble_root": mean(lambda s: s["ms_assemble"]),
+                     "exchange": "every device copies its shard to the root's gather buffer (hipMemcpyPeerAsync / same-device copy)",
+                     "exchange_bytes": int(8 * n_pairs), "clock": "HIP events on each device's stream, inside the library"},
+        "peer_access": stats[-1]["peer_access"],
+        "shards": {"pairs_min_max": [min(p["n_pairs"] for p in last), max(p["n_pairs"] for p in last)],
+                   "cells_min_max": [min(p["n_cells"] for p in last), max(p["n_cells"] for p in last)]},
+        "create_s": t_create, "upload_s": upload_s,
+    }
+    line["value_wall_incl_init"] = n_pairs / (t_create + upload_s + elapsed / a.steps)
+    if needs_residues:
+        line["roofline"], line["kernel_source_hash"] = aligned_roofline(
+            a, world, tot("n_alignments"), tot("n_cells"), tot("n_residue_bytes"), tot("n_distinct_alignments"), tot("n_distinct_cells"),
+            ms_align_max, [ms_align_min, ms_align_max])
+    else:
+        nb = packed.n_genomes * packed.words_per_row * 8 + 16 * packed.n_genomes + 8 * n_pairs
+        t = mean(lambda s: s["ms_total"]) / 1e3
+        line["roofline"] = {"bound": "hbm", "achieved": nb / t / 1e9 if t > 0 else 0.0, "peak": 8000.0 * world, "unit": "GB/s",
+                            "frac": nb / t / 1e9 / (8000.0 * world) if t > 0 else 0.0, "traffic": None, "algorithmic_bytes_per_fill": nb}
+    if a.verify_pairs > 0 and n_pairs > 0:
+        import numpy as np
+        line["verified"] = verify_sample(packed, a.metric, a.verify_pairs, lambda cond: np.asarray(out)[cond])
+    line["valid"] = bool(line.get("verified", {}).get("bit_exact", True))
+    print(json.dumps(line), flush=True)
+    mc.close()
+    if not line["valid"]:
+        sys.exit(1)
+
+
+def aligned_roofline(a, world, n_aln, n_cells, n_rbytes, n_daln, n_dcells, ms_align, align_span):
+    """The `roofline` object of an aai / peq fill: the K4 launches of one fill; multi-GPU: work of all devices / slowest device's time."""
+    # this rank-set's K4 launches of one fill; multi-GPU: work of all ranks / slowest rank's time
+    algo_bytes = n_rbytes + 16 * n_aln
+    per_gpu_time = ms_align / 1e3
+    hbm_achieved = algo_bytes / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
+    gcups = n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
+    # The bound that binds: VALU issue, priced per instruction class.  A SIMD retires a wave64 VALU instruction in 4 clocks
+    # (16 lanes/clk) for v_max_f64, SDWA / DPP / VOP3 forms, compares and v_addc, and in 2 (32 lanes/clk) for the plain VOP2
+    # add / sub / and / or once several waves share it (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json: 4.15 and
+    # 2.15 in unmixed streams).  The cell is 10 instructions: four v_max_f64 acting as lexicographic (score, tie-break tag, path
+    # statistics) maxima and two SDWA adds from the profile (4 clocks each), four tag / open-penalty fix-ups -- v_or, v_or,
+    # v_and, v_sub (2 each): 32 issue clocks per 64 cells, 4,915 GCUPS.  r01-r03 priced all ten at 4 clocks (3,932 GCUPS): a
+    # probe of identical waves running a mixed stream in lockstep measures 4.0 per instruction whatever the mix
+    # (tests/hw/valu_mix.hip).  The kernel itself refutes that ceiling: its counters show 11.49 executed VALU instructions per
+    # cell (the 11-instruction compare cell of long column genes, step prologues, idle lanes), and 11.49 x 64-lane
+    # instructions at this line's rate are 3.8 clocks per instruction per SIMD -- below 4 -- so its waves, which are not in
+    # lockstep, do get the cheap class cheaper; and turning two VOP3 re-tags into VOP2 ones (r04) took 6 % off the fill at the
+    # same instruction count.  `frac_at_4_clk_per_instruction` is the r03 figure's successor, for continuity only.
+    instr_per_cell = 10
+    issue_clk_per_cell = 6 * 4 + 4 * 2
+    peak_gcups = 256 * 4 * 64 * 2.4e9 / issue_clk_per_cell / 1e9
+    roof = {
+        "bound": "valu", "achieved": gcups / 1e3, "peak": peak_gcups / 1e3, "unit": "TCUPS (DP cells/s; VALU issue clocks per cell priced per instruction class)",
+        "frac": gcups / peak_gcups, "traffic": None,
+        "kernel": "k_nw_systolic_tier<TIER,RULE,cell> / k_nw_systolic<W,RULE> (all launches of one fill, per GPU)",
+        "instr_per_cell": instr_per_cell, "issue_clk_per_cell": issue_clk_per_cell, "peak_gcups": peak_gcups, "achieved_gcups": gcups,
+        "frac_at_4_clk_per_instruction": gcups / (256 * 4 * 16 * 2.4e9 / instr_per_cell / 1e9),
+        "issue_rate_source": "profiles/valu_issue_rate.json (unmixed: 4.15 / 2.15 clk), profiles/r04/final/counters.json (11.49 executed VALU instructions per cell), "
+                             "profiles/r04/experiments/retag_one_op_ab.txt, valu_mix_probe.txt",
+        "ms_kernels_per_fill": ms_align, "n_alignments": n_aln, "dp_cells": n_cells,
+        # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
+        "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells, "gcups_per_gpu": gcups,
+        "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": 8000.0, "unit": "GB/s", "frac": hbm_achieved / 8000.0,
+                "algorithmic_bytes_per_fill": algo_bytes,
+                "note": "sum(la+lb) residues + 16 B per alignment over the kernels' time: far below HBM speed by construction "
+                        "(the recurrence is integer-VALU bound, no MFMA: there is no dense contraction)"},
+    }
+    if align_span:
+        roof["ms_kernels_min_max_over_ranks"] = align_span
+    src_hash = kernel_source_hash()
+    try:                                              # PMC traffic measured offline for this exact workload AND these sources
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
+            for e in json.load(fh)["entries"]:
+                if e["workload"] == f"synth({a.genomes},{a.phams}) -m {a.metric}" and e["n_gpus"] == world:
+                    if e.get("kernel_source_hash") == src_hash:
+                        roof["traffic"] = e["traffic_bytes_per_fill"]
+                        roof["traffic_source"] = e["source"]
+                    else:
+                        roof["traffic_stale"] = {"bytes_per_fill": e["traffic_bytes_per_fill"], "source": e["source"],
+                                                             "taken_on_kernel_source_hash": e.get("kernel_source_hash")}
+    except (OSError, KeyError, ValueError):
+        pass
+    return roof, src_hash
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and a.route == "rank":
+        sys.exit(spawn_ranks(a))                               # before anything below: no torch, no library, no GPU in this process
+    if a.route == "process":
+        if world != 1:
+            sys.exit("--route process is ONE process driving all GPUs: do not start it under a launcher")
+        return main_one_process(a)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (WORLD_SIZE={world})")
         a.gpus = world
+    if os.environ.get("PC_BENCH_CHILD_PROBE") == "1":         # tests/: the spawn plumbing alone, on a machine without a GPU
+        return child_probe(a, rank, world)
 
     # PC_BENCH_FORCE_DIST=1: the whole N > 1 flow -- process group, sharded fill, exchange, assembly, the all_reduce bookkeeping of
     # this file -- with ONE rank, so that it runs through RCCL on a one-GPU box (two ranks cannot share a GPU under RCCL)
@@ -294,7 +514,8 @@ def main():
     line = {
         "metric": "genome-pairs/sec", "value": value, "unit": "genome-pairs/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "int32", "data": "synthetic",
+        "dtype": "int32", "data": "synthetic", "route": "rank",
+        "ranks_seen": dist.get_world_size() if multi else 1, "devices_visible": torch.cuda.device_count(),
         "config": {"workload": f"synth({a.genomes},{a.phams}) -m {a.metric}: full N x N distance-matrix fill; `value` = fills with the genomes resident in "
                                f"HBM and the matrix left in HBM (upload and D2H excluded: see value_wall)",
                    "dist_mode": (dist_mode() if a.metric in ("aai", "peq") else "pairs") if multi else None,
@@ -306,58 +527,7 @@ def main():
                                   + (" [REHEARSAL: ONE rank, exchange forced (PC_BENCH_FORCE_DIST)]" if multi and world == 1 else "")},
     }
     if a.metric in ("aai", "peq"):
-        # this rank-set's K4 launches of one fill; multi-GPU: work of all ranks / slowest rank's time
-        algo_bytes = n_rbytes + 16 * n_aln
-        per_gpu_time = ms_align / 1e3
-        hbm_achieved = algo_bytes / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
-        gcups = n_dcells / world / per_gpu_time / 1e9 if per_gpu_time > 0 else 0.0
-        # The bound that binds: VALU issue, priced per instruction class.  A SIMD retires a wave64 VALU instruction in 4 clocks
-        # (16 lanes/clk) for v_max_f64, SDWA / DPP / VOP3 forms, compares and v_addc, and in 2 (32 lanes/clk) for the plain VOP2
-        # add / sub / and / or once several waves share it (tests/hw/valu_rate.hip -> profiles/valu_issue_rate.json: 4.15 and
-        # 2.15 in unmixed streams).  The cell is 10 instructions: four v_max_f64 acting as lexicographic (score, tie-break tag, path
-        # statistics) maxima and two SDWA adds from the profile (4 clocks each), four tag / open-penalty fix-ups -- v_or, v_or,
-        # v_and, v_sub (2 each): 32 issue clocks per 64 cells, 4,915 GCUPS.  r01-r03 priced all ten at 4 clocks (3,932 GCUPS): a
-        # probe of identical waves running a mixed stream in lockstep measures 4.0 per instruction whatever the mix
-        # (tests/hw/valu_mix.hip).  The kernel itself refutes that ceiling: its counters show 11.49 executed VALU instructions per
-        # cell (the 11-instruction compare cell of long column genes, step prologues, idle lanes), and 11.49 x 64-lane
-        # instructions at this line's rate are 3.8 clocks per instruction per SIMD -- below 4 -- so its waves, which are not in
-        # lockstep, do get the cheap class cheaper; and turning two VOP3 re-tags into VOP2 ones (r04) took 6 % off the fill at the
-        # same instruction count.  `frac_at_4_clk_per_instruction` is the r03 figure's successor, for continuity only.
-        instr_per_cell = 10
-        issue_clk_per_cell = 6 * 4 + 4 * 2
-        peak_gcups = 256 * 4 * 64 * 2.4e9 / issue_clk_per_cell / 1e9
-        line["roofline"] = {
-            "bound": "valu", "achieved": gcups / 1e3, "peak": peak_gcups / 1e3, "unit": "TCUPS (DP cells/s; VALU issue clocks per cell priced per instruction class)",
-            "frac": gcups / peak_gcups, "traffic": None,
-            "kernel": "k_nw_systolic_tier<TIER,RULE,cell> / k_nw_systolic<W,RULE> (all launches of one fill, per GPU)",
-            "instr_per_cell": instr_per_cell, "issue_clk_per_cell": issue_clk_per_cell, "peak_gcups": peak_gcups, "achieved_gcups": gcups,
-            "frac_at_4_clk_per_instruction": gcups / (256 * 4 * 16 * 2.4e9 / instr_per_cell / 1e9),
-            "issue_rate_source": "profiles/valu_issue_rate.json (unmixed: 4.15 / 2.15 clk), profiles/r04/final/counters.json (11.49 executed VALU instructions per cell), "
-                                 "profiles/r04/experiments/retag_one_op_ab.txt, valu_mix_probe.txt",
-            "ms_kernels_per_fill": ms_align, "n_alignments": n_aln, "dp_cells": n_cells,
-            # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank
-            "n_distinct_alignments": n_daln, "dp_cells_computed": n_dcells, "gcups_per_gpu": gcups,
-            "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": 8000.0, "unit": "GB/s", "frac": hbm_achieved / 8000.0,
-                    "algorithmic_bytes_per_fill": algo_bytes,
-                    "note": "sum(la+lb) residues + 16 B per alignment over the kernels' time: far below HBM speed by construction "
-                            "(the recurrence is integer-VALU bound, no MFMA: there is no dense contraction)"},
-        }
-        if align_span:
-            line["roofline"]["ms_kernels_min_max_over_ranks"] = align_span
-        src_hash = kernel_source_hash()
-        line["kernel_source_hash"] = src_hash
-        try:                                              # PMC traffic measured offline for this exact workload AND these sources
-            with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
-                for e in json.load(fh)["entries"]:
-                    if e["workload"] == f"synth({a.genomes},{a.phams}) -m {a.metric}" and e["n_gpus"] == world:
-                        if e.get("kernel_source_hash") == src_hash:
-                            line["roofline"]["traffic"] = e["traffic_bytes_per_fill"]
-                            line["roofline"]["traffic_source"] = e["source"]
-                        else:
-                            line["roofline"]["traffic_stale"] = {"bytes_per_fill": e["traffic_bytes_per_fill"], "source": e["source"],
-                                                                 "taken_on_kernel_source_hash": e.get("kernel_source_hash")}
-        except (OSError, KeyError, ValueError):
-            pass
+        line["roofline"], line["kernel_source_hash"] = aligned_roofline(a, world, n_aln, n_cells, n_rbytes, n_daln, n_dcells, ms_align, align_span)
     else:
         nb = packed.n_genomes * packed.words_per_row * 8 + 16 * packed.n_genomes + 8 * n_pairs
         t = ms_dev / 1e3
@@ -380,22 +550,8 @@ def main():
                              "value_wall_incl_init = pairs / (init_s + upload_s + one step): what ONE matrix costs a job that has to start its ranks first")
 
     if a.verify_pairs > 0 and n_pairs > 0:
-        # sampled check of the assembled matrix against the oracle (random pairs over the whole triangle)
-        from oracle import oracle as O
-        import numpy as np
-        rng = np.random.default_rng(12345)
-        n = packed.n_genomes
-        s_idx = rng.integers(0, n - 1, a.verify_pairs)
-        t_idx = rng.integers(0, n, a.verify_pairs)
-        lo, hi = np.minimum(s_idx, t_idx), np.maximum(s_idx, t_idx)
-        keep = lo < hi
-        lo, hi = lo[keep], hi[keep]
-        cond = lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)
-        got = out[torch.as_tensor(cond, device=out.device)].cpu().numpy()
-        want = O.pairs(packed, a.metric, lo, hi, as_distance=True)
-        line["verified"] = {"pairs": int(lo.size), "how": "random pairs of the full matrix vs oracle/pc_oracle.c",
-                            "max_abs_diff": float(np.max(np.abs(got - want))), "bit_exact": bool(np.array_equal(got, want)),
-                            "parity": parity_note(a.metric)}
+        line["verified"] = verify_sample(packed, a.metric, a.verify_pairs,
+                                         lambda cond: out[torch.as_tensor(cond, device=out.device)].cpu().numpy())
     if world == 1:
         # SURVEY 8(d)'s wall time of one matrix: upload + kernels + D2H of the condensed vector (host clock, second of two)
         for _ in range(2):

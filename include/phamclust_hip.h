@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PC_VERSION 150   /* 0.4.0: strip-mined passes for long column genes, tier launches, small-task workgroups */
+#define PC_VERSION 151   /* 0.5.0: pc_multi_peer_access */
 
 typedef enum {
     PC_OK = 0,
@@ -211,6 +211,18 @@ typedef struct pc_multi pc_multi;
 int pc_multi_create(pc_multi** out, const int* device_ids, int n_dev);
 void pc_multi_destroy(pc_multi* m);
 int pc_multi_devices(const pc_multi* m);
+/* How each device's shard will reach the root, decided in pc_multi_create and never hidden: granted[r] (pc_multi_devices() entries,
+ * may be NULL) = one of the values below.  Returns the number of devices whose copies are NOT device to device (the runtime stages
+ * them through host memory: correct, slower) and leaves their reasons -- the runtime's own error text, one line per device -- for
+ * pc_last_error(); 0 when every copy is a peer copy or stays on the root's device.  The reference has no counterpart: its workers
+ * return results through joblib's pickling (matrix.py:488-491). */
+typedef enum {
+    PC_PEER_SAME_DEVICE = 2,    /* the root itself, or another context on the root's GPU (rehearsal): device-to-device copy */
+    PC_PEER_ENABLED = 1,        /* hipDeviceEnablePeerAccess granted (or was already on): hipMemcpyPeerAsync over xGMI     */
+    PC_PEER_UNAVAILABLE = 0,    /* hipDeviceCanAccessPeer says no                                                         */
+    PC_PEER_FAILED = -1         /* the query or the enable call returned an error                                          */
+} pc_peer_access;
+int pc_multi_peer_access(const pc_multi* m, int32_t* granted);
 int pc_multi_upload(pc_multi* m, const pc_packed* genomes, int with_residues);
 int pc_multi_upload_residues(pc_multi* m, const pc_packed* genomes);
 int pc_multi_set_tie_rule(pc_multi* m, int rule);

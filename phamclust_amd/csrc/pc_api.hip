@@ -1835,6 +1835,8 @@ struct pc_multi {
     std::vector<pc_ctx*> ctx;               // ctx[0] is the root: it holds the gather buffer, the assembled matrix and the pinned result
     DevBuf b_gather;                        // root device: world x stride doubles
     std::vector<DevBuf> b_shard;            // device r: its shard, stride doubles (allocated on that device)
+    std::vector<int32_t> peer;              // device r -> root: PC_PEER_* (how its shard will travel), see pc_multi_peer_access
+    std::vector<std::string> peer_note;     // the runtime's own words where access was refused
     bool uploaded = false, residues = false;
 };
 
@@ -1869,16 +1871,27 @@ extern "C" int pc_multi_create(pc_multi** out, const int* device_ids, int n_dev)
         if (rc != PC_OK) { pc_multi_destroy(m); return rc; }
         m->ctx.push_back(c);
     }
-    // peer access root <- every other device where the hardware offers it (the copies work without, staged by the runtime)
+    // peer access root <- every other device where the hardware offers it.  Without it the copies still work (the runtime stages
+    // them through host memory), only slower: so a refusal is no error, but it is RECORDED per device (pc_multi_peer_access) --
+    // a node whose exchange crawls must be able to say why.
+    m->peer.assign((size_t)n_dev, PC_PEER_SAME_DEVICE);
+    m->peer_note.assign((size_t)n_dev, std::string());
     for (int r = 1; r < n_dev; ++r) {
         if (m->ctx[r]->device == m->ctx[0]->device) continue;
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, m->ctx[r]->device, m->ctx[0]->device) == hipSuccess && can) {
-            PcDeviceGuard guard(m->ctx[r]->device);
-            const hipError_t e = hipDeviceEnablePeerAccess(m->ctx[0]->device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-            else (void)hipGetLastError();
-        } else (void)hipGetLastError();
+        hipError_t e = hipDeviceCanAccessPeer(&can, m->ctx[r]->device, m->ctx[0]->device);
+        if (e != hipSuccess) {
+            m->peer[r] = PC_PEER_FAILED;
+            m->peer_note[r] = std::string("hipDeviceCanAccessPeer: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            continue;
+        }
+        if (!can) { m->peer[r] = PC_PEER_UNAVAILABLE; m->peer_note[r] = "hipDeviceCanAccessPeer says no: copies staged by the runtime"; continue; }
+        PcDeviceGuard guard(m->ctx[r]->device);
+        e = hipDeviceEnablePeerAccess(m->ctx[0]->device, 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) m->peer[r] = PC_PEER_ENABLED;
+        else { m->peer[r] = PC_PEER_FAILED; m->peer_note[r] = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
+        (void)hipGetLastError();
     }
     *out = m;
     return PC_OK;
@@ -1895,6 +1908,26 @@ extern "C" void pc_multi_destroy(pc_multi* m) {
 }
 
 extern "C" int pc_multi_devices(const pc_multi* m) { return m ? (int)m->ctx.size() : -1; }
+
+// How each device's shard reaches the root (decided once, in pc_multi_create): granted[r] = PC_PEER_*.  Returns the number of
+// devices whose copies will NOT go device to device (PC_PEER_UNAVAILABLE / PC_PEER_FAILED); their reasons, one per line, are left
+// for pc_last_error() -- as a note, not a failure: the call's status is that count (>= 0) or PC_ERR_ARG.
+extern "C" int pc_multi_peer_access(const pc_multi* m, int32_t* granted) {
+    if (!m) { pc_set_error("pc_multi_peer_access: NULL"); return PC_ERR_ARG; }
+    int staged = 0;
+    std::string note;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        if (granted) granted[r] = m->peer[r];
+        if (m->peer[r] == PC_PEER_UNAVAILABLE || m->peer[r] == PC_PEER_FAILED) {
+            ++staged;
+            char line[256];
+            snprintf(line, sizeof line, "device %d -> root %d: %s\n", m->ctx[r]->device, m->ctx[0]->device, m->peer_note[r].c_str());
+            note += line;
+        }
+    }
+    if (staged) pc_set_error("%s", note.c_str());
+    return staged;
+}
 
 // Every device gets the same packed genomes (they are replicated: 0.2 GB at N = 5,000), in parallel.  with_residues = 0: part 1 only
 // (all the set metrics need); an aai / peq fill uploads the residues on demand.

@@ -29,6 +29,12 @@ _warned = False
 def draw_heatmap(matrix, colors=None, midpoint=0.5, filename=None):
     """Render ``matrix`` as a heatmap to ``filename`` (.html or an image type kaleido supports)."""
     global _warned
+    import os
+    if os.environ.get("PHAMCLUST_NO_HEATMAPS") == "1":          # visualisation is outside the accelerated path: tests of N = 10,000
+        if not _warned:                                          # pipelines do not render 500 cluster heatmaps through kaleido
+            logging.info("PHAMCLUST_NO_HEATMAPS=1 - heatmaps are skipped")
+            _warned = True
+        return None
     try:
         import plotly.express as px
     except ImportError:

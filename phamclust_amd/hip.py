@@ -50,7 +50,7 @@ EXPORTS = ["pc_version", "pc_test_hooks", "pc_last_error", "pc_ctx_create", "pc_
            "pc_shard_pairs", "pc_shard_stride", "pc_fill", "pc_fill_borrow", "pc_fill_dev", "pc_fill_shard_dev", "pc_assemble_dev",
            "pc_align_pairs", "pc_last_align_ms", "pc_round6_probe", "pc_set_tie_rule", "pc_get_tie_rule", "pc_shard_table", "pc_target_costs",
            "pc_plan_dev", "pc_align_slice_dev", "pc_reduce_dev", "pc_upload_sets", "pc_upload_residues", "pc_set_plan_budget", "pc_chunk_plan",
-           "pc_variant_width", "pc_last_set_kernel", "pc_multi_create", "pc_multi_destroy", "pc_multi_devices", "pc_multi_upload",
+           "pc_variant_width", "pc_last_set_kernel", "pc_multi_create", "pc_multi_destroy", "pc_multi_devices", "pc_multi_peer_access", "pc_multi_upload",
            "pc_multi_upload_residues", "pc_multi_set_tie_rule", "pc_multi_fill_borrow"]
 NEEDS_RESIDUES = ("aai", "peq", "aai_ppos")
 
@@ -118,6 +118,7 @@ def load():
     L.pc_multi_destroy.argtypes = [vp]
     L.pc_multi_destroy.restype = None
     L.pc_multi_devices.argtypes = [vp]
+    L.pc_multi_peer_access.argtypes = [vp, _i32p]
     L.pc_multi_upload.argtypes = [vp, ctypes.POINTER(PcPacked), ctypes.c_int]
     L.pc_multi_upload_residues.argtypes = [vp, ctypes.POINTER(PcPacked)]
     L.pc_multi_set_tie_rule.argtypes = [vp, ctypes.c_int]
@@ -452,7 +453,23 @@ class MultiContext:
         ids = np.ascontiguousarray(self.device_ids, dtype=np.int32)
         rc = self._lib.pc_multi_create(ctypes.byref(self._h), _ptr(ids, _i32p), int(ids.shape[0]))
         if rc != 0:
-            raise HipLibraryError(f"libphamclust_hip: status {rc}: {self._lib.pc_last_error().decode()}")
+            # (the other multi-GPU route starts fresh CHILD processes, one per GPU; this process is never re-executed)
+            raise HipLibraryError(f"libphamclust_hip: status {rc}: {self._lib.pc_last_error().decode()} -- devices {self.device_ids} could not "
+                                  f"all be opened from one process; PHAMCLUST_MULTI=launcher runs the same shard as one process per GPU "
+                                  f"(torch.distributed.run, one RCCL gather)")
+
+    PEER_ACCESS = {2: "same-device", 1: "peer", 0: "staged (no peer access)", -1: "staged (peer access failed)"}
+
+    def peer_access(self):
+        """How each device's shard reaches ``device_ids[0]``: a list of ``{"device", "access", "code"}`` plus the runtime's reasons
+        for every copy that is NOT device to device (``pc_multi_peer_access``).  Never silent: ``fill`` stats and the CLI log carry it."""
+        codes = np.zeros(self.n_devices, dtype=np.int32)
+        staged = self._lib.pc_multi_peer_access(self._h, _ptr(codes, _i32p))
+        if staged < 0:
+            self._check(staged)
+        note = self._lib.pc_last_error().decode().strip() if staged else ""
+        return {"devices": [{"device": d, "code": int(c), "access": self.PEER_ACCESS[int(c)]} for d, c in zip(self.device_ids, codes)],
+                "staged_through_host": int(staged), "note": note}
 
     _check = Context._check
     _struct = staticmethod(Context._struct)
@@ -520,5 +537,5 @@ class MultiContext:
             return out
         per = [s.as_dict() for s in stats]
         merged = dict(per[0], per_device=per, ms_exchange=float(x_ms.value), ms_assemble=float(a_ms.value), n_devices=self.n_devices,
-                      ms_total=max(p["ms_total"] for p in per))
+                      ms_total=max(p["ms_total"] for p in per), peer_access=self.peer_access())
         return out, merged

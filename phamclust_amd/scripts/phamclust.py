@@ -181,7 +181,15 @@ class _Run:
                 line += (f"; rank 0: {st['n_alignments']} alignments, {st['n_cells']:.3e} DP cells, "
                          f"{st['n_distinct_cells'] / max(st['ms_align'], 1e-6) / 1e6:.0f} GCUPS in the alignment kernels")
             log.info(line)
-            if self.metric in _metrics.PARITY_NOTE:          # say it wherever these numbers leave the program
+            peers = st.get("peer_access")                    # one process, N GPUs: how every shard reached the root -- never silent
+            if peers:
+                ways = ", ".join(f"{d['device']}: {d['access']}" for d in peers["devices"])
+                log.info(f"exchange: device -> root copies {ways}; {st.get('ms_exchange', 0.0):.2f} ms (slowest copy)"
+                         + (f"; STAGED THROUGH HOST for {peers['staged_through_host']} device(s): {peers['note']} "
+                            f"(PHAMCLUST_MULTI=launcher gathers over RCCL instead)" if peers["staged_through_host"] else "")
+                         + ("" if any(d["code"] == 1 for d in peers["devices"]) or peers["staged_through_host"] else
+                            " [all contexts on the root's GPU: the cross-device branch did not run]"))
+            if self.metric in _metrics.PARITY_NOTE:         # say it wherever these numbers leave the program
                 log.info(f"parity: {_metrics.parity_note(self.metric)}")
             if TIMELINE is not None:                         # the matrix stage, split (matrix_de_novo's own clocks)
                 TIMELINE.stamps += [("pack", st.get("pack_s", 0.0)), ("process_group_and_context", max(0.0, wall - st.get("pack_s", 0.0) - st.get("upload_s", 0.0) - st.get("fill_s", 0.0))),
@@ -315,6 +323,21 @@ def main(argv=None):
     global TIMELINE
     TIMELINE = startup.Timeline()
     TIMELINE.mark("imports")
+    # What this run tells the library layers through the environment (PHAMCLUST_GPUS / _NO_TORCH / _DEVICE) is THIS RUN's: the old
+    # values come back when main() returns, so that a caller of main() -- a test, a notebook -- does not find its later
+    # matrix_de_novo calls redirected to N GPUs, or its later `import torch` next to a HIP runtime bound without it.
+    saved_env = {key: os.environ.get(key) for key in ("PHAMCLUST_GPUS", "PHAMCLUST_GPU_IDS", "PHAMCLUST_NO_TORCH", "PHAMCLUST_DEVICE")}
+    try:
+        _run(args, argv)
+    finally:
+        for key, value in saved_env.items():
+            if value is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = value
+
+
+def _run(args, argv):
     rank, _, world = distributed.env_world()
     gpus_note = None
     if args.gpus > 1 and world == 1:
@@ -339,6 +362,9 @@ def main(argv=None):
                                               env={"PHAMCLUST_T0": repr(TIMELINE.t_launch), "PHAMCLUST_FORCE_GPUS": "1"}))
         if n_gpus > 1:
             os.environ["PHAMCLUST_GPUS"] = str(n_gpus)             # matrix_de_novo: devices 0..N-1 from this process (PHAMCLUST_GPU_IDS names others)
+            if args.device is not None:
+                gpus_note = (gpus_note or "") + (f"; --device {args.device} is IGNORED: {n_gpus} GPUs from one process are devices 0..{n_gpus - 1} "
+                                                 f"(name others with PHAMCLUST_GPU_IDS)")
         else:
             os.environ.pop("PHAMCLUST_GPUS", None); os.environ.pop("PHAMCLUST_GPU_IDS", None)
     if world == 1:

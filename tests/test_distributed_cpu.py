@@ -189,3 +189,58 @@ def test_dist_mode_switch(monkeypatch):
     monkeypatch.setenv("PHAMCLUST_DIST_MODE", "rows")
     with pytest.raises(ValueError):
         D.dist_mode()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` by itself: the parent starts the ranks as a CHILD launcher before it has touched a GPU
+# (it replaces the reference's in-process worker pool, matrix.py:471-472,488-491, whose parent also only hands out work).
+# PC_BENCH_CHILD_PROBE=1 makes the ranks stop after joining their (gloo) group, so the plumbing runs where there is no GPU.
+# ---------------------------------------------------------------------------------------------------------
+def _run_bench_parent(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PC_BENCH_CHILD_PROBE="1", PC_BENCH_BACKEND="gloo", **extra_env)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    done = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")]
+    return done, lines
+
+
+def test_bench_parent_spawns_the_ranks_as_a_child_without_touching_the_gpu():
+    done, lines = _run_bench_parent({}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--genomes", "64")
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert len(lines) == 1, done.stdout                         # ONE line on the parent's stdout: rank 0's, relayed
+    line = lines[0]
+    assert line["ranks_seen"] == 2 and line["n_gpus"] == 2
+    assert sorted(r["rank"] for r in line["ranks"]) == [0, 1] and len({r["pid"] for r in line["ranks"]}) == 2
+    for r in line["ranks"]:                                     # the parent's own arguments reached every rank unchanged
+        assert r["argv"] == ["--gpus", "2", "--steps", "1", "--warmup", "0", "--genomes", "64"]
+    by = line["launched_by"]
+    assert by["parent_modules_touching_gpu"] == [] and by["child_exit_status"] == 0
+    assert "torch.distributed.run" in by["how"]
+
+
+def test_bench_parent_relays_a_failing_rank():
+    done, lines = _run_bench_parent({"PC_BENCH_CHILD_PROBE_FAIL": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert done.returncode != 0
+    assert lines and lines[0]["launched_by"]["child_exit_status"] != 0
+
+
+def test_bench_parent_source_makes_no_gpu_call():
+    """spawn_ranks itself: no torch, no hip binding, no build -- read off its source."""
+    import ast
+    src = open(os.path.join(REPO, "bench.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "spawn_ranks")
+    imported = set()
+    for node in ast.walk(fn):
+        if isinstance(node, ast.Import):
+            imported |= {a.name for a in node.names}
+        if isinstance(node, ast.ImportFrom):
+            imported.add(node.module)
+    assert imported == {"subprocess", "phamclust_amd.distributed"}, imported
+    main = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    first_import = min(n.lineno for n in ast.walk(main) if isinstance(n, (ast.Import, ast.ImportFrom)))
+    spawn_call = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "spawn_ranks")
+    assert spawn_call < first_import                             # main() hands over before it imports anything

@@ -15,6 +15,22 @@ import pytest
 from conftest import ALL_METRICS, SET_METRICS, golden_file, read_adjacency_condensed, read_lower_triangle
 
 pytestmark = pytest.mark.gpu
+
+
+def _py_round6(arr):
+    """CPython's ``round(v, 6)`` of every element -- the reference's rounding (e.g. metrics.py:50-53) -- without 12.5 M interpreter
+    calls: ``rint(v * 1e6) / 1e6`` IS that value whenever v * 1e6 is not within 1e-3 of a half (the scaled value's rounding error is
+    < 1e-9 there, so both pick the same integer k, and k / 1e6 is one correctly-rounded division either way); the elements that are
+    near a half, plus a random 50,000 as a guard on this argument, go through CPython's round itself."""
+    arr = np.asarray(arr, dtype=np.float64)
+    scaled = arr * 1e6
+    out = np.rint(scaled) / 1e6
+    near_half = np.abs(np.abs(scaled - np.floor(scaled)) - 0.5) < 1e-3
+    idx = np.flatnonzero(near_half)
+    out[idx] = [round(v, 6) for v in arr[idx].tolist()]
+    guard = np.random.default_rng(6).integers(0, arr.size, min(arr.size, 50000))
+    assert np.array_equal(out[guard], np.array([round(v, 6) for v in arr[guard].tolist()]))
+    return out
 TOL = 1e-6
 
 
@@ -663,7 +679,7 @@ def test_full_size_peq_properties(gpu_ctx, native_built):
     assert np.array_equal(gpu_ctx.fill("peq", as_distance=False), peq)
     af, aai, jc = (gpu_ctx.fill(m, as_distance=False) for m in ("af", "aai", "jc"))
     product = af * aai                                   # both factors are the rounded similarities (metrics.py:247-252)
-    py_round = lambda arr: np.array([round(v, 6) for v in arr.tolist()])      # CPython's round: the reference's semantics
+    py_round = _py_round6                                                     # CPython's round: the reference's semantics
     assert np.array_equal(peq, py_round(product))
     assert not peq[jc == 0.0].any() and not aai[jc == 0.0].any() and not af[jc == 0.0].any()
     dist = gpu_ctx.fill("peq", as_distance=True)
@@ -708,7 +724,7 @@ def test_config2_peq_2000_full_fill(gpu_ctx, native_built):
     assert np.array_equal(gpu_ctx.fill("peq", as_distance=False), peq)
     assert peq.min() >= 0.0 and peq.max() <= 1.0
     af, aai, jc = (gpu_ctx.fill(m, as_distance=False) for m in ("af", "aai", "jc"))
-    py_round = lambda arr: np.array([round(v, 6) for v in arr.tolist()])
+    py_round = _py_round6
     assert np.array_equal(peq, py_round(af * aai))
     assert not peq[jc == 0.0].any() and (aai[jc > 0.0] > 0.0).all()
     dist = gpu_ctx.fill("peq", as_distance=True)
@@ -1680,3 +1696,95 @@ def test_multi_context_one_process_many_devices(native_built):
                 assert np.array_equal(multi.fill("jc", as_distance=False), O.fill(packed, "jc", as_distance=False))
     with pytest.raises(hip.HipLibraryError):
         hip.MultiContext([0, 99])
+
+
+def _bench_line(argv, env_extra, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PC_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env)
+    assert proc.returncode == 0, (proc.stdout[-1500:], proc.stderr[-3000:])
+    lines = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-1500:]
+    return lines[0]
+
+
+def test_bench_gpus_2_by_itself_spawns_two_ranks(native_built):
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver runs `--gpus 1`): the parent starts
+    torch.distributed.run as a child before touching the GPU, two ranks meet, fill their shards, ONE gather, assembly, and the
+    parent relays rank 0's line.  This box has one GPU, so the ranks share it over the gloo rehearsal transport (RCCL refuses two
+    ranks on one device); on a node with >= 2 GPUs the same command runs over RCCL.  Replaces the reference's joblib fan-out
+    (matrix.py:471-472,488-491)."""
+    d = _bench_line(["--gpus", "2", "--genomes", "301", "--steps", "2", "--warmup", "1", "--verify-pairs", "3000", "--cpu-seconds", "0"],
+                    {"PC_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["route"] == "rank" and d["devices_visible"] >= 1
+    assert d["verified"]["bit_exact"] is True and d["valid"] is True
+    assert d["launched_by"]["parent_modules_touching_gpu"] == [] and d["launched_by"]["child_exit_status"] == 0
+    assert d["shards"]["pairs_min_max"][0] > 0 and d["stage_ms"]["exchange_rank0"] > 0
+
+
+@pytest.mark.parametrize("metric", ["peq", "jc"])
+def test_bench_route_process_drives_the_devices_from_one_process(native_built, metric):
+    """`bench.py --gpus 2 --route process`: hip.MultiContext (pc_multi_*) timed by the same harness, so that on a multi-GPU node the
+    peer-copy exchange can be put next to the RCCL gather.  Here: two contexts on the one GPU; the line says so, and says how
+    every shard travelled (pc_multi_peer_access)."""
+    d = _bench_line(["--gpus", "2", "--route", "process", "--genomes", "301", "--steps", "2", "--warmup", "1", "--verify-pairs", "3000",
+                     "--cpu-seconds", "0", "--metric", metric], {"PC_BENCH_DEVICE_IDS": "0,0"})
+    assert d["route"] == "process" and d["n_gpus"] == 2 and d["device_ids"] == [0, 0]
+    assert d["verified"]["bit_exact"] is True and "REHEARSAL" in d["config"]["parallelism"]
+    peers = d["peer_access"]
+    assert [p["access"] for p in peers["devices"]] == ["same-device", "same-device"] and peers["staged_through_host"] == 0
+    assert sum(d["shards"]["pairs_min_max"]) == 301 * 300 // 2 and d["stage_ms"]["assemble_root"] > 0
+    assert d["roofline"]["frac"] > 0
+
+
+def test_multi_context_reports_peer_access(native_built):
+    """pc_multi_create records, per device, whether its copies to the root are peer copies -- and the answer is part of every
+    fill's stats.  With two or more GPUs on the box, the cross-device branch (hipMemcpyPeerAsync after hipDeviceEnablePeerAccess)
+    runs for real and must give the single-GPU matrix bit for bit."""
+    import torch
+    from phamclust_amd import hip
+    from phamclust_amd.synth import synth_packed
+    packed = synth_packed(157, 600, seed=8)
+    with hip.Context(0) as one:
+        one.upload(packed)
+        want = {m: np.asarray(one.fill(m)).copy() for m in ("jc", "af", "peq")}
+    ids = [0, 1] if torch.cuda.device_count() >= 2 else [0, 0]
+    with hip.MultiContext(ids) as multi:
+        acc = multi.peer_access()
+        assert [d["device"] for d in acc["devices"]] == ids and acc["devices"][0]["access"] == "same-device"
+        if ids[1] != ids[0]:
+            assert acc["devices"][1]["code"] in (1, 0, -1)
+            assert (acc["staged_through_host"] == 0) == (acc["devices"][1]["code"] == 1) and bool(acc["note"]) == bool(acc["staged_through_host"])
+        else:
+            assert acc["staged_through_host"] == 0 and acc["note"] == ""
+        multi.upload(packed)
+        for m, w in want.items():
+            got, st = multi.fill(m, want_stats=True)
+            assert np.array_equal(got, w), m
+            assert st["peer_access"] == acc
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_reference_written_synth200(gpu_ctx, synth200_packed, metric):
+    """SURVEY 8(d) config 1's live-reference subset, through the C-ABI: the first 200 genomes of synth(2000,5000), 19,900 pairs per
+    metric, against files the reference itself wrote (tests/golden/synth200/, matrix.py:432-497 + scripts/phamclust.py:254-268).
+    gcs / jc / pocp ``==``; af / aai / peq <= 1e-6 (north_star's tolerance, written here) -- and, beyond the contract, equal."""
+    from conftest import read_lower_triangle, synth200_file
+    names, gold, diag = read_lower_triangle(synth200_file(metric))
+    assert names == synth200_packed.names and gold.shape == (19900,) and not diag.any()
+    got = np.asarray(gpu_ctx.upload(synth200_packed).fill(metric, as_distance=True))
+    if metric in ("gcs", "jc", "pocp"):
+        assert np.array_equal(got, gold)
+    else:
+        assert np.max(np.abs(got - gold)) <= 1e-6
+        assert np.array_equal(got, gold)
+    # the pipeline reads the file back as its cache (scripts/phamclust.py:254-257): what matrix_de_novo returns must print to it
+    from phamclust_amd.matrix import SymMatrix
+    m = SymMatrix.from_condensed(names, got, is_distance=True)
+    assert m.get_weight(names[3], names[150]) == gold[3 * 200 - 3 * 4 // 2 + (150 - 3 - 1)]

@@ -40,6 +40,23 @@ def test_c_oracle_vs_golden(O, small_packed, metric):
 
 
 @pytest.mark.parametrize("metric", ALL_METRICS)
+def test_c_oracle_vs_reference_written_synth200(O, synth200_packed, metric):
+    """19,900 pairs per metric written by the LIVE reference (matrix_de_novo over metrics.py:26-253, matrix.py:432-497; the file
+    is what scripts/phamclust.py:262 caches) for the first 200 genomes of configs[1]'s workload: gcs / jc / pocp must be equal,
+    af / aai / peq within 1e-6 (north_star) -- they are in fact equal too.  aai / peq files are class "oracle_nw" (the reference's
+    loop over this oracle's aligner; parasail is absent)."""
+    from conftest import synth200_file
+    names, gold, diag = read_lower_triangle(synth200_file(metric))
+    assert names == synth200_packed.names and len(names) == 200 and gold.shape == (19900,) and not diag.any()
+    got = O.fill(synth200_packed, metric, as_distance=True)
+    if metric in ("gcs", "jc", "pocp"):
+        assert np.array_equal(got, gold)
+    else:
+        assert np.max(np.abs(got - gold)) <= 1e-6
+        assert np.array_equal(got, gold)                     # stronger than the contract, and true
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
 def test_python_restatement_vs_golden(O, small_genomes, metric):
     names, gold, _ = read_lower_triangle(golden_file(metric))
     f = O.PY_METRICS[metric]
