@@ -68,6 +68,8 @@ def lib():
                                        ctypes.c_char_p, ctypes.c_char_p, _i32p]
         L.pco_nw_batch.argtypes = [_u8p, _i64p, _i32p, _i32p, ctypes.c_int64, _i32p, _i32p, _i32p, ctypes.c_int]
         L.pco_round6.argtypes = [ctypes.c_double]
+        L.pco_div_million_mismatches.argtypes = [ctypes.c_int64]
+        L.pco_div_million_mismatches.restype = ctypes.c_int64
         L.pco_round6.restype = ctypes.c_double
         L.pco_pair.argtypes = [ctypes.POINTER(_Packed), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.pco_pair.restype = ctypes.c_double
@@ -146,6 +148,11 @@ def nw_batch(residues, seq_off, a_idx, b_idx, nthreads=0):
     if rc != 0:
         raise ValueError("pco_nw_batch failed")
     return sc, ni, nd
+
+
+def div_million_mismatches(k_max):
+    """Integers k in [0, k_max] for which the device's three-instruction k / 1e6 (pc_div_million) would differ from the division."""
+    return int(lib().pco_div_million_mismatches(int(k_max)))
 
 
 def round6(x):

@@ -1414,6 +1414,9 @@ static int fill_aligned(pc_ctx* c, int metric, int ppos, int as_distance, double
     return PC_OK;
 }
 
+#ifndef PC_COL_MIN_N
+#define PC_COL_MIN_N 3000        // genomes from which k_sparse_col takes over from k_sparse_tile64 (r05 sweep: profiles/r05/experiments/sparse_col.txt)
+#endif
 static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
     if (!c || !c->uploaded) { pc_set_error("fill: upload first"); return PC_ERR_STATE; }
     if (metric < PC_GCS || metric > PC_AAI_PPOS) { pc_set_error("fill: metric %d", metric); return PC_ERR_ARG; }
@@ -1450,7 +1453,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     // The 64 x 64 kernel takes "sum == 0" for "no shared pham" and sums in 32 bits: it needs every entry value >= 1 (a
     // genome with an empty translation fails that for af) and genome totals below 2^31; else af falls back to the
     // 32 x 32 kernel / the shared-pham walker (crossover ~3,500 genomes), pocp to the popcount tiles.
-    enum { K_POPC, K_SPARSE32, K_SPARSE64, K_WALKER };
+    enum { K_POPC, K_SPARSE32, K_SPARSE64, K_WALKER, K_SPARSE_COL };
     int kernel = K_POPC;
     {
         const char* set_force = getenv("PC_SET_KERNEL");                   // (read per fill: the tests switch it between launches)
@@ -1463,7 +1466,12 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
+        // r05: gcs / jc on large matrices: the column form of the counting mode (k_sparse_col: the masks over a block of targets stay
+        // in LDS for a run of source tiles, no barrier per tile) -- while its masks fit (<= 7,680 phams with two holders)
+        const bool col_ok = counts && s64_ok && pc_sparse_col_lds(d.sp_W * 64) > 0;
+        if (kernel == K_SPARSE64 && col_ok && area >= (int64_t)PC_COL_MIN_N * PC_COL_MIN_N) kernel = K_SPARSE_COL;
         if (set_force) {
+            if (!strcmp(set_force, "sparsecol") && col_ok) kernel = K_SPARSE_COL;
             if (!strcmp(set_force, "popc") && metric != PC_AF) kernel = K_POPC;
             else if (!strcmp(set_force, "sparse") && !counts) kernel = K_SPARSE32;
             else if (!strcmp(set_force, "sparse64") && s64_ok) kernel = K_SPARSE64;
@@ -1471,7 +1479,12 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         }
     }
     if (metric < PC_AAI) c->last_set_kernel = kernel;
-    if ((metric == PC_GCS || metric == PC_JC) && kernel == K_SPARSE64) {
+    if ((metric == PC_GCS || metric == PC_JC) && kernel == K_SPARSE_COL) {
+        rc = pc_launch_sparse_col(metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC, d, c->shard, out, as_distance, condensed, st);
+        if (rc != PC_OK) return rc;
+        PC_HIP(hipEventRecord(c->ev[3], st));
+        local.n_chunks = 1;
+    } else if ((metric == PC_GCS || metric == PC_JC) && kernel == K_SPARSE64) {
         rc = pc_launch_sparse64(metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC, d, c->shard, out, as_distance, condensed, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));

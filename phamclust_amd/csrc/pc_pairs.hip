@@ -59,12 +59,24 @@ __device__ __noinline__ double pc_round6_exact(double x) {
 // result is that integer divided by 1e6 -- the very division the exact routine ends with.  Only values that close to a
 // decimal tie (two in a million) take the 128-bit integer route.  Every metric's epilogue runs this once or twice per genome
 // pair; with the exact routine alone it was most of the sparse pocp / af kernel's time.
+// k / 1e6 for an integer k in [0, 2^22], correctly rounded, in three instructions instead of the ~12 of a full fp64 division:
+// q0 = k * RN(1e-6) is within an ulp of the quotient, r = k - q0 * 1e6 is exact in one fma, and q0 + r * RN(1e-6) rounds to the
+// correctly rounded quotient (Markstein's final step: the divisor is a constant whose reciprocal is correctly rounded).  Held to
+// `k / 1000000.0` for EVERY k of that range on the host (tests/test_oracle.py::test_markstein_division_by_a_million, plain C
+// arithmetic) and on the device (tests/test_gpu_parity.py::test_round6_every_millionth: round6 of every k / 1e6 is itself).
+__device__ __forceinline__ double pc_div_million(double k) {
+    const double R = 1.0 / 1000000.0;
+    const double q0 = k * R;
+    const double r = __builtin_fma(-q0, 1000000.0, k);
+    return __builtin_fma(r, R, q0);
+}
+
 __device__ __forceinline__ double pc_round6(double x) {
     if (!(x > 0.0)) return 0.0;
     if (x < 2.0) {
         const double y = x * 1.0e6;
         const double k = __builtin_rint(y);
-        if (__builtin_fabs(y - k) <= 0.5 - 0x1p-30) return k / 1000000.0;
+        if (__builtin_fabs(y - k) <= 0.5 - 0x1p-30) return pc_div_million(k);
     }
     return pc_round6_exact(x);
 }
@@ -952,6 +964,194 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 #undef S6_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_tile64 launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// K1 for large matrices (r05): gcs / jc with the masks over a block of 64 TARGET genomes kept in LDS across a run of source tiles,
+// and every accumulator row owned by ONE wave -- no barrier per tile.
+//
+// What the r05 split of k_sparse_tile64's counting mode showed (profiles/r05/experiments/set_tile_time_split.txt, sparse_col.txt;
+// N = 20,000, 1.51 ms): 0.75 ms of a launch is neither probing nor the epilogue but what a tile does before it can probe -- per mask
+// chunk two dependent rounds of global loads (rank table, then entries) for both sides, a 20-KB clear, the atomicOr build, three
+// barriers -- with the VALU busy 0.82 of the time.  Here
+//   * a workgroup (16 waves) takes a UNIT = one block of 64 target genomes x a run of S7_SEG source tiles.  The targets' entries are
+//     loaded, and the masks over them (all phams at once: 8 B per pham with at least two holders) built, ONCE per unit;
+//   * per source tile a wave loads the entries of ITS four source rows (their ranges one tile ahead), reads their masks, and adds:
+//     |S n T| is symmetric, so only the sources probe, and a source row's accumulator row is written by the wave that owns the row
+//     alone -- its direct adds go to LDS (atomics: two entries of a row may hit the same target), its broadcast adds stay in a
+//     register per row -- and the same wave finishes the row's 64 pairs (fp64 epilogue, one coalesced store).  Nothing in a tile
+//     waits for another wave: no barrier, and at 8 waves per SIMD another wave is always ready;
+//   * units are dealt so that XCD x takes the target blocks ty = x mod 8 and the runs of a block from the diagonal down (the
+//     diagonal tiles -- pairs inside a cluster share ~85 phams, ten times the work -- start first).
+// pocp / af stay on k_sparse_tile64: their second direction (the targets' values) adds into rows of OTHER waves, which needs the
+// barriers back, and fetching its masks -- the tile's sources -- from a transposed bitmap (built and measured: pocp 2.29 against
+// 2.28 ms, af 2.62 against 2.46) costs a 64-line gather per load instruction.
+// Needs 8 B x phams-with-two-holders of LDS beside the accumulators: up to 7,680 such phams; beyond, or for small matrices, the
+// kernels above run.  No MFMA: this is a sparse join, ~3 shared phams per pair.
+// ---------------------------------------------------------------------------------
+#define S7_SEG 8                                                  // source tiles per unit
+#define S7_B 2                                                    // 64-entry batches of a row held in registers (a row's ~100 entries)
+#define S7_WAVES 16
+#define S7_RPW (S6_T / S7_WAVES)                                  // rows (of either side) a wave owns
+template <int MODE>
+__global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int P64, int nty) {
+    static_assert(MODE == S6_GCS || MODE == S6_JC, "counting modes only");
+    extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+    uint32_t* colmask = sp_lds;                                                    // [P64][2]: which of the block's 64 targets hold the pham
+    uint32_t* acc = sp_lds + 2 * P64;                                              // [64 sources][65]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // unit of this workgroup
+    const unsigned xcd = blockIdx.x & 7u, kk = blockIdx.x >> 3;
+    const unsigned nty8 = ((unsigned)nty + 7u) / 8u;
+    const int ty = (int)((kk % nty8) * 8u + xcd), run = (int)(kk / nty8);
+    if (ty >= nty) return;
+    const int k0 = ty * S6_T;
+    const int klast = min(k0 + S6_T, sh.nown) - 1;
+    const int live = (pc_owned(sh, klast) + S6_T - 1) / S6_T;                      // source tiles with a pair s < t in them: s0 < the block's last target
+    const int tx1 = live - run * S7_SEG;
+    if (tx1 <= 0) return;
+    const int tx0 = max(0, tx1 - S7_SEG);
+
+    // ---- once per unit: the masks over the targets
+    const int gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;           // lane l <-> target row l, for the whole unit
+    const uint32_t tot_t_l = gt_l >= 0 ? (uint32_t)d.nph[gt_l] : 0u;
+    const int64_t lbase_l = (!condensed && gt_l >= 0) ? sh.lbase[k0 + lane] : 0;
+    {
+        uint32_t rl_t = 0, rh_t = 0;
+        if (gt_l >= 0) { rl_t = d.ent_off[gt_l]; rh_t = d.sp_end[gt_l]; }
+        uint32_t lo_t[S7_RPW], hi_t[S7_RPW];
+        int ph_t[S7_RPW][S7_B];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) {
+            const int r = wave + S7_WAVES * rr;
+            lo_t[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_t, r); hi_t[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_t, r);
+        }
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr)
+#pragma unroll
+            for (int b = 0; b < S7_B; ++b) {
+                const uint32_t et = lo_t[rr] + (uint32_t)(64 * b + lane);
+                ph_t[rr][b] = et < hi_t[rr] ? d.sp_pham[et] : -1;
+            }
+        for (int i = tid * 4; i < 2 * P64; i += 256 * S7_WAVES) *(uint4*)&colmask[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < S6_T * S6_LD; i += 64 * S7_WAVES) acc[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) {
+            const int r = wave + S7_WAVES * rr;
+            const uint32_t bit = 1u << (r & 31); const int half = r >> 5;
+#pragma unroll
+            for (int b = 0; b < S7_B; ++b) if (ph_t[rr][b] >= 0) atomicOr(&colmask[2 * ph_t[rr][b] + half], bit);
+            for (uint32_t e0 = lo_t[rr] + 64u * S7_B; e0 < hi_t[rr]; e0 += 64u) {            // rows with more entries than the registers hold
+                const uint32_t e = e0 + (uint32_t)lane;
+                if (e < hi_t[rr]) atomicOr(&colmask[2 * d.sp_pham[e] + half], bit);
+            }
+        }
+    }
+    // the sources' entry ranges, one tile ahead
+    uint32_t rl_s = 0, rh_s = 0;
+    { const int g = tx0 * S6_T + lane; if (g < d.N) { rl_s = d.ent_off[g]; rh_s = d.sp_end[g]; } }
+    __syncthreads();                                                                // masks complete: from here on no wave waits for another
+
+    // one probe step of source row r: 64 entries (one per lane), each with the 64-bit mask m of the targets that hold its pham.  Up
+    // to two hits the lane adds itself (LDS); more are BROADCAST: the mask becomes the EXEC mask of one v_add into hs, which lane l
+    // holds for target l (k_sparse_tile64's step; raising the threshold with a loop per lane -- 3, 4, 6 hits -- changed nothing)
+    auto step = [&](int r, uint2 m, uint32_t& hs) {
+        const int pc = __popc(m.x) + __popc(m.y);
+        if (pc > 0 && pc <= 2) {
+            const unsigned long long mm = ((unsigned long long)m.y << 32) | m.x;
+            const int o1 = __builtin_ctzll(mm), o2 = 63 - __builtin_clzll(mm);
+            atomicAdd(&acc[r * S6_LD + o1], 1u);
+            if (pc == 2) atomicAdd(&acc[r * S6_LD + o2], 1u);
+        }
+        unsigned long long heavy = __ballot(pc > 2);
+        while (heavy) {
+            const int k = __builtin_ctzll(heavy);
+            asm("s_bitset0_b64 %0, %1" : "+s"(heavy) : "s"(k));
+            const unsigned long long mk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m.y, k) << 32) |
+                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m.x, k);
+            // (every lane of the workgroup is active here -- wave-uniform control flow -- so EXEC is all ones before and after)
+            asm volatile("s_mov_b64 exec, %1\n\tv_add_u32 %0, %0, 1\n\ts_mov_b64 exec, -1" : "+v"(hs) : "s"(mk));
+        }
+    };
+
+#pragma unroll 1
+    for (int tx = tx0; tx < tx1; ++tx) {
+        const int s0 = tx * S6_T;
+        uint32_t lo_s[S7_RPW], hi_s[S7_RPW];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) {
+            const int r = wave + S7_WAVES * rr;
+            lo_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_s, r); hi_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_s, r);
+        }
+        int ph_s[S7_RPW][S7_B];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr)
+#pragma unroll
+            for (int b = 0; b < S7_B; ++b) {
+                const uint32_t es = lo_s[rr] + (uint32_t)(64 * b + lane);
+                ph_s[rr][b] = es < hi_s[rr] ? d.sp_pham[es] : -1;
+            }
+        rl_s = 0; rh_s = 0;                                                         // the next tile's ranges: in flight while this one is probed
+        { const int g = s0 + S6_T + lane; if (tx + 1 < tx1 && g < d.N) { rl_s = d.ent_off[g]; rh_s = d.sp_end[g]; } }
+        // all of the tile's mask reads first, then the adds (an LDS read does not move across an LDS atomic: masks and accumulators
+        // are one array to the compiler)
+        uint2 ms[S7_RPW][S7_B];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr)
+#pragma unroll
+            for (int b = 0; b < S7_B; ++b) ms[rr][b] = ph_s[rr][b] >= 0 ? *(const uint2*)&colmask[2 * ph_s[rr][b]] : make_uint2(0u, 0u);
+        uint32_t hs[S7_RPW];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) {
+            const int r = wave + S7_WAVES * rr;
+            hs[rr] = 0u;
+#pragma unroll
+            for (int b = 0; b < S7_B; ++b) step(r, ms[rr][b], hs[rr]);
+            for (uint32_t e0 = lo_s[rr] + 64u * S7_B; e0 < hi_s[rr]; e0 += 64u) {
+                const uint32_t e = e0 + (uint32_t)lane;
+                uint2 m = make_uint2(0u, 0u);
+                if (e < hi_s[rr]) m = *(const uint2*)&colmask[2 * d.sp_pham[e]];
+                step(r, m, hs[rr]);
+            }
+        }
+        // finish the wave's own rows: lane l <-> target l.  (The wave's LDS adds above and the reads below are one in-order queue.)
+        uint32_t cons_q[S7_RPW];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) cons_q[rr] = acc[(wave + S7_WAVES * rr) * S6_LD + lane];
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) acc[(wave + S7_WAVES * rr) * S6_LD + lane] = 0u;     // (left clean for the next tile, pairs on or below the diagonal too)
+#pragma unroll
+        for (int rr = 0; rr < S7_RPW; ++rr) {
+            const int s = s0 + wave + S7_WAVES * rr;                               // wave-uniform
+            if (s >= d.N) continue;
+            const int t = gt_l;
+            if (t < 0 || s >= t) continue;
+            const uint32_t tot = (uint32_t)d.nph[s] + tot_t_l;
+            const int64_t idx = condensed ? (int64_t)s * d.N - (int64_t)s * (s + 1) / 2 + (t - s - 1) : lbase_l + s;
+            out[idx] = pc_set_value<MODE == S6_GCS ? PC_GCS : PC_JC>((int)(cons_q[rr] + hs[rr]), (int)tot, as_distance);   // metrics.py:45-53 (gcs), 75-80 (jc)
+        }
+    }
+}
+
+// LDS the column kernel takes for a collection with P64 mask entries; 0: it cannot run (masks beyond 7,680 phams)
+size_t pc_sparse_col_lds(int P64) {
+    if (P64 > 7680) return 0;
+    return (size_t)P64 * 8 + (size_t)S6_T * S6_LD * 4;
+}
+int pc_launch_sparse_col(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
+    if (sh.nown <= 0 || d.N <= 1) return PC_OK;
+    const int P64 = d.sp_W * 64;
+    const size_t lds = pc_sparse_col_lds(P64);
+    if (!lds || (mode != S6_GCS && mode != S6_JC)) { pc_set_error("k_sparse_col: mode %d, %d mask entries", mode, P64); return PC_ERR_LIMIT; }
+    const int nty = (sh.nown + S6_T - 1) / S6_T, ntx = (d.N + S6_T - 1) / S6_T;
+    const unsigned runs = (unsigned)((ntx + S7_SEG - 1) / S7_SEG);
+    dim3 grid(((unsigned)nty + 7u) / 8u * 8u * runs), block(64 * S7_WAVES);
+    if (mode == S6_GCS) hipLaunchKernelGGL((k_sparse_col<S6_GCS>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty);
+    else hipLaunchKernelGGL((k_sparse_col<S6_JC>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pc_set_error("k_sparse_col launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;
 }
 

@@ -416,7 +416,7 @@ class Context:
     def last_align_ms(self):
         return float(self._lib.pc_last_align_ms(self._h))
 
-    SET_KERNELS = {0: "popc", 1: "sparse", 2: "sparse64", 3: "walker", -1: None}
+    SET_KERNELS = {0: "popc", 1: "sparse", 2: "sparse64", 3: "walker", 4: "sparsecol", -1: None}
 
     def last_set_kernel(self):
         """Kernel family the selector gave the last gcs / jc / pocp / af fill (the names PC_SET_KERNEL takes)."""

@@ -1245,31 +1245,34 @@ def test_out_of_memory_plan_becomes_smaller_chunks(native_built):
     -DPC_TEST_HOOKS twin (libphamclust_hip_hooks.so, PHAMCLUST_NATIVE_VARIANT=hooks), so this runs in its own process."""
     import subprocess
     import sys
+    import tempfile
+    from phamclust_amd.synth import synth_packed
     code = r'''
 import numpy as np, sys
 sys.path.insert(0, %r)
 from phamclust_amd import hip
 from phamclust_amd.synth import synth_packed
-from oracle import oracle as O
 pk = synth_packed(260, 1500, seed=3)
 assert hip.load().pc_test_hooks() == 1, "not the hooks build"
 with hip.Context(0) as ctx:
     ctx.upload(pk)
     got, st = ctx.fill("peq", want_stats=True)
     assert st["n_chunks"] >= 2, st
-    assert np.array_equal(got, O.fill(pk, "peq")), "chunked-after-OOM fill differs from the oracle"
+    assert np.array_equal(got, np.load(sys.argv[1])), "chunked-after-OOM fill differs from the oracle"
     print("chunks", st["n_chunks"])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19), PHAMCLUST_NATIVE_VARIANT="hooks")       # ~0.1 M alignments: the one-piece plan's A * 8-byte buffers are ~0.9 MB
-    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert run.returncode == 0, run.stdout + run.stderr
-    assert "chunks" in run.stdout
     # the release library has no such switch: the same environment changes nothing there
-    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19))
-    env.pop("PHAMCLUST_NATIVE_VARIANT", None)
     code2 = code.replace('== 1, "not the hooks build"', '== 0, "the release build carries test hooks"').replace('assert st["n_chunks"] >= 2, st', 'assert st["n_chunks"] == 1, st')
-    run = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=600)
-    assert run.returncode == 0, run.stdout + run.stderr
+    env = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19), PHAMCLUST_NATIVE_VARIANT="hooks", PHAMCLUST_NO_TORCH="1")       # ~0.1 M alignments: the one-piece plan's A * 8-byte buffers are ~0.9 MB
+    env2 = dict(os.environ, PC_FAKE_OOM_ABOVE=str(1 << 19), PHAMCLUST_NO_TORCH="1")
+    env2.pop("PHAMCLUST_NATIVE_VARIANT", None)
+    with tempfile.TemporaryDirectory() as tmp:
+        want = os.path.join(tmp, "want.npy")
+        np.save(want, _oracle().fill(synth_packed(260, 1500, seed=3), "peq"))
+        runs = [subprocess.Popen([sys.executable, "-c", c, want], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for c, e in ((code, env), (code2, env2))]
+        outs = [r.communicate(timeout=600)[0] for r in runs]
+    assert runs[0].returncode == 0 and "chunks" in outs[0], outs[0]
+    assert runs[1].returncode == 0, outs[1]
 
 
 def test_two_part_upload(gpu_ctx, native_built):
@@ -1393,19 +1396,21 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
     want = {(m, dist): O.fill(packed, m, dist) for m in ("pocp", "af") for dist in (True, False)}
     stream = torch.cuda.current_stream().cuda_stream
     try:
-        for kernel in ("popc", "sparse", "sparse64", "walker"):
+        for kernel in ("popc", "sparse", "sparse64", "sparsecol", "walker"):
             os.environ["PC_SET_KERNEL"] = kernel                             # read per fill
             gpu_ctx.upload(packed, residues=False)
             for (m, dist), w in want.items():
                 assert np.array_equal(gpu_ctx.fill(m, dist), w), (kernel, m, dist)
-            if kernel in ("popc", "sparse64"):                               # gcs / jc: popcount tiles, or the sparse tiles' counting mode
+                assert gpu_ctx.last_set_kernel() == kernel or (kernel, m) == ("popc", "af") or kernel == "sparsecol", (kernel, m, gpu_ctx.last_set_kernel())   # (sparsecol: gcs / jc only)
+            if kernel in ("popc", "sparse64", "sparsecol"):                  # gcs / jc: popcount tiles, or the sparse tiles' counting mode
                 for m in ("gcs", "jc"):
                     for dist in (True, False):
                         assert np.array_equal(gpu_ctx.fill(m, dist), O.fill(packed, m, dist)), (kernel, m, dist)
+                        assert gpu_ctx.last_set_kernel() == kernel
             gpu_ctx.set_shard(1, 3)
             t_rank, t_lbase = gpu_ctx.shard_table()
             n = packed.n_genomes
-            for m in ("pocp", "af") + (("jc",) if kernel in ("popc", "sparse64") else ()):
+            for m in ("pocp", "af") + (("jc",) if kernel in ("popc", "sparse64", "sparsecol") else ()):
                 buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
                 gpu_ctx.fill_shard_dev(m, True, buf.data_ptr(), stream)
                 torch.cuda.synchronize()
@@ -1418,12 +1423,14 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
                     assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), (kernel, m, t)
             gpu_ctx.set_shard(0, 1)
         # one mask chunk of more than 64 KB of LDS (5,952 < phams <= 7,680)
-        os.environ["PC_SET_KERNEL"] = "sparse64"
         mid = _set_kernel_case(rng, 120, 25000, wide_rows=(9,))
         assert 5952 < mid.words_per_row * 64 <= 7680                          # (again the vocabulary, see above)
-        gpu_ctx.upload(mid, residues=False)
-        for m in ("pocp", "af", "gcs", "jc"):
-            assert np.array_equal(gpu_ctx.fill(m), O.fill(mid, m)), m
+        for kernel in ("sparse64", "sparsecol"):
+            os.environ["PC_SET_KERNEL"] = kernel
+            gpu_ctx.upload(mid, residues=False)
+            for m in ("pocp", "af", "gcs", "jc"):
+                assert np.array_equal(gpu_ctx.fill(m), O.fill(mid, m)), (kernel, m)
+        os.environ["PC_SET_KERNEL"] = "sparse64"
         # no pham with two holders: the kernel's lists (phams that can be shared at all) are empty
         from phamclust_amd.genome import Genome
         from phamclust_amd.pack import pack_genomes
@@ -1500,8 +1507,9 @@ def test_sparse64_chunked_instances_and_forced_split(gpu_ctx, native_built):
     stream = torch.cuda.current_stream().cuda_stream
     try:
         os.environ["PC_SET_KERNEL"] = "sparse64"
-        for label, packed, chunks in (("big", big, None), ("mid", mid, None), ("mid", mid, "2"), ("mid", mid, "3"), ("big", big, "5")):
-            if chunks is None:
+        for label, packed, chunks in (("big", big, None), ("mid", mid, None), ("mid", mid, "2"), ("mid", mid, "3"), ("big", big, "5"), ("mid", mid, "col")):
+            os.environ["PC_SET_KERNEL"] = "sparsecol" if chunks == "col" else "sparse64"    # (k_sparse_col: its largest mask array, 7,680 phams)
+            if chunks in (None, "col"):
                 os.environ.pop("PC_S64_CHUNKS", None)
             else:
                 os.environ["PC_S64_CHUNKS"] = chunks                        # read per launch
@@ -1615,20 +1623,24 @@ def test_real_collection_shape_full_matrix(gpu_ctx, native_built):
     picked = {}
     n = pk.n_genomes
     rng = np.random.default_rng(8)
+    filled = {}
     for metric in ALL_METRICS:
         got, st = gpu_ctx.fill(metric, want_stats=True)
-        got = np.asarray(got).copy()
-        if metric == "aai":                                    # (the checker needs ~1 min of 16 cores per alignment metric at this size:
-            lo = rng.integers(0, n - 1, 20000); hi = rng.integers(0, n, 20000)       # peq gets the whole matrix, aai 20,000 random pairs)
-            lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
+        got = filled[metric] = np.asarray(got).copy()
+        if metric in ("aai", "peq"):                           # (the checker needs ~1 min of 16 cores per alignment metric for the whole
+            lo = rng.integers(0, n - 1, 30000); hi = rng.integers(0, n, 30000)       # matrix at this size: 30,000 random pairs each, and
+            lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)                          # below the WHOLE peq matrix through its definition)
             keep = lo < hi; lo, hi = lo[keep], hi[keep]
             assert np.array_equal(got[lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)], O.pairs(pk, metric, lo, hi)), metric
         else:
             assert np.array_equal(got, O.fill(pk, metric)), metric
         picked[metric] = gpu_ctx.last_set_kernel() if metric in SET_METRICS else (st["n_distinct_alignments"], st["n_alignments"])
+    # every peq value: round(1 - round(af, 6) * round(aai, 6), 6) (metrics.py:247-253) from the af matrix (whole, against the oracle
+    # above) and the aai matrix of an independent fill
+    assert np.array_equal(filled["peq"], _py_round6(1.0 - np.asarray(gpu_ctx.fill("af", as_distance=False)) * np.asarray(gpu_ctx.fill("aai", as_distance=False))))
     assert picked["peq"][0] < 0.7 * picked["peq"][1]                                       # most alignments are repeats of identical proteins
     try:
-        for kernel in ("popc", "sparse", "sparse64", "walker"):
+        for kernel in ("popc", "sparse", "sparse64", "sparsecol", "walker"):
             os.environ["PC_SET_KERNEL"] = kernel
             for metric in SET_METRICS:
                 assert np.array_equal(gpu_ctx.fill(metric), O.fill(pk, metric)), (kernel, metric)
@@ -1645,27 +1657,35 @@ def test_launch_policy_switches_change_no_value(native_built):
     import json
     import subprocess
     import sys
+    import tempfile
+    from phamclust_amd.synth import synth_real
     code = r'''
 import json, sys
 import numpy as np
 sys.path.insert(0, %r)
 from phamclust_amd import hip
 from phamclust_amd.synth import synth_real
-from oracle import oracle as O
 pk = synth_real(120, seed=12)
 assert (np.diff(pk.seq_off) > 4096).any()
 with hip.Context(0) as ctx:
     ctx.upload(pk)
     got, st = ctx.fill("peq", want_stats=True)
-    assert np.array_equal(got, O.fill(pk, "peq")), "peq differs from the oracle"
+    assert np.array_equal(got, np.load(sys.argv[1])), "peq differs from the oracle"
     print(json.dumps({"launches": st["n_align_launches"], "tasks": st["n_tasks"]}))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = {}
-    for name, env in (("default", {}), ("per_class", {"PC_FUSE": "0", "PC_SMALL_LAUNCH_MIN": "1"}), ("no_modes_no_strip", {"PC_SMALL_MODES": "0", "PC_STRIP": "0"}),
-                      ("strips_in_line", {"PC_STRIP_STREAMS": "0"}), ("one_strip_region_fits", {"PC_SLAB_BUDGET": "300000"})):
-        run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-        assert run.returncode == 0, (name, run.stdout[-1500:], run.stderr[-3000:])
-        seen[name] = json.loads(run.stdout.strip().splitlines()[-1])
+    settings = (("default", {}), ("per_class", {"PC_FUSE": "0", "PC_SMALL_LAUNCH_MIN": "1"}), ("no_modes_no_strip", {"PC_SMALL_MODES": "0", "PC_STRIP": "0"}),
+                ("strips_in_line", {"PC_STRIP_STREAMS": "0"}), ("one_strip_region_fits", {"PC_SLAB_BUDGET": "300000"}))
+    with tempfile.TemporaryDirectory() as tmp:
+        want = os.path.join(tmp, "want.npy")
+        np.save(want, _oracle().fill(synth_real(120, seed=12), "peq"))        # the oracle's matrix once, for all of them
+        for wave in (settings[:3], settings[3:]):                              # side by side, at most three processes (the box allows six on its GPU)
+            procs = [(name, subprocess.Popen([sys.executable, "-c", code, want], env=dict(os.environ, PHAMCLUST_NO_TORCH="1", **env),
+                                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for name, env in wave]
+            for name, proc in procs:
+                out, err = proc.communicate(timeout=900)
+                assert proc.returncode == 0, (name, out[-1500:], err[-3000:])
+                seen[name] = json.loads(out.strip().splitlines()[-1])
     assert seen["default"]["tasks"] == seen["per_class"]["tasks"] and seen["default"]["launches"] < seen["per_class"]["launches"], seen
 
 

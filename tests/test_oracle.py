@@ -338,3 +338,11 @@ def test_checker_refuses_to_answer_with_switched_conventions():
     finally:
         O.set_gap()                                             # ... until the defaults are restored
     assert np.array_equal(O.fill(pk, "peq"), base)
+
+
+def test_markstein_division_by_a_million(O):
+    """The set-metric epilogue ends in k / 1e6 (round(x, 6), e.g. metrics.py:50-53); the device computes it as a multiply and two
+    fused multiply-adds (csrc/pc_pairs.hip: pc_div_million).  In plain C arithmetic: the same value as the division for EVERY k a
+    similarity or distance can produce (k <= 2 * 10^6; checked to 2^22).  The device side of the same claim:
+    tests/test_gpu_parity.py::test_round6_every_millionth."""
+    assert O.div_million_mismatches(1 << 22) == 0

@@ -2,7 +2,8 @@
 """Build csrc/libphamclust_hip_<name>.so from the current sources with extra compiler flags, for A/B runs in one GPU call
 (PHAMCLUST_NATIVE_VARIANT=<name> loads it: phamclust_amd/hip.py).
 
-usage: build_variant.py NAME [-DFLAG=VALUE ...]
+usage: build_variant.py NAME [--only pc_pairs.hip[,pc_api.hip]] [-DFLAG=VALUE ...]
+--only: compile just these units with the flags and link them with the release build's objects of the others (seconds, not a minute).
 """
 import os
 import subprocess
@@ -17,7 +18,16 @@ def main(name, flags):
     os.makedirs(out_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs, objs = [], []
+    only = None
+    if "--only" in flags:
+        i = flags.index("--only")
+        only = set(flags[i + 1].split(","))
+        flags = flags[:i] + flags[i + 2:]
+        b.build_all()                                        # the release objects the variant links against
     for src, obj_name, extra in b.HIP_UNITS:
+        if only is not None and src not in only:
+            objs.append(os.path.join(b.CSRC, obj_name))
+            continue
         obj = os.path.join(out_dir, obj_name)
         if src.startswith("pc_nw") and any(f.startswith(("-DPC_MAX_BUILTIN", "-DPC_CELL_ORDER")) for f in flags):
             extra = extra + ["-ffinite-math-only"]          # __builtin_fmax without canonicalising v_max_f64 x, x, x (pc_nw_systolic.h)

@@ -52,7 +52,7 @@ for metric in ("gcs", "jc", "pocp", "af", "aai", "peq"):
     else:
         row["selector_picked"] = ctx.last_set_kernel()
         forced = {}
-        for k in ("popc", "sparse", "sparse64", "walker"):
+        for k in ("popc", "sparse", "sparse64", "sparsecol", "walker"):
             os.environ["PC_SET_KERNEL"] = k
             ms = min(ctx.fill_dev(metric, True, out_dev.data_ptr(), stream)["ms_total"] for _ in range(a.steps))
             torch.cuda.synchronize()

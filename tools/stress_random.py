@@ -48,7 +48,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
     ctx.upload(packed, residues=bool(rng.random() < 0.5))              # two-part upload: the residues follow on demand
     ctx.set_plan_budget(int(rng.choice([0, 56, 56 * 7, 56 * 60, 56 * 2000])))   # 0: automatic; tiny: one target genome per chunk
     os.environ["PC_POPC_TILE"] = str(rng.choice(["32", "64"]))
-    os.environ["PC_SET_KERNEL"] = str(rng.choice(["popc", "sparse", "sparse64", "walker"]))   # pocp / af kernel, read per fill
+    os.environ["PC_SET_KERNEL"] = str(rng.choice(["popc", "sparse", "sparse64", "sparsecol", "walker"]))   # pocp / af kernel, read per fill
     os.environ["PC_S64_CHUNKS"] = str(rng.choice(["1", "2", "3"]))
     os.environ["PC_PIPE"] = str(rng.choice(["", "0", "2", "3", "8"]))       # strip-mined launches: the launcher's choice, one row per wave, pipelined over n waves
     for metric in ("gcs", "jc", "pocp", "af", "aai", "peq", "aai_ppos"):
