@@ -353,6 +353,21 @@ def aligned_roofline(a, world, n_aln, n_cells, n_rbytes, n_daln, n_dcells, ms_al
     if align_span:
         roof["ms_kernels_min_max_over_ranks"] = align_span
     src_hash = kernel_source_hash()
+    # the same quantity from a rocprofv3 --kernel-trace of this command (first K4 start -> last K4 end per fill; tools/summarize_profile.py
+    # k4span): a tracked file, so that `frac` can be redone from profiles/ alone.  Quoted with the device code it was taken on.
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "final", "bench_peq5000_k4_span.txt")), reverse=True):
+        if world != 1 or (a.genomes, a.phams, a.metric) != (5000, 5000, "peq"):
+            break
+        text = open(path).read()
+        m = re.search(r"span, mean over fills [0-9.]+: ([0-9.]+) ms", text)
+        h = re.search(r"kernel_source_hash\): (\w+)", text)
+        if m:
+            span = float(m.group(1))
+            roof["rocprof_k4_span"] = {"source": os.path.relpath(path, REPO), "span_ms_per_fill": span, "frac_from_span": n_dcells / span / 1e6 / peak_gcups,
+                                       "taken_on_kernel_source_hash": h.group(1) if h else None, "same_device_code": bool(h and h.group(1) == src_hash)}
+        break
     try:                                              # PMC traffic measured offline for this exact workload AND these sources
         with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
             for e in json.load(fh)["entries"]:

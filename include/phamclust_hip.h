@@ -261,7 +261,8 @@ int pc_variant_width(int lb);
 float pc_last_align_ms(const pc_ctx* ctx);
 
 /* Which kernel family the selector gave the last gcs / jc / pocp / af fill of this context: 0 popcount tiles, 1 sparse tiles
- * 32 x 32, 2 sparse tiles 64 x 64, 3 shared-pham walker; -1 before the first such fill.  (The selector reads the collection:
+ * 32 x 32, 2 sparse tiles 64 x 64, 3 shared-pham walker, 4 the column kernel (gcs / jc: target-block masks kept in LDS over a run
+ * of source tiles); -1 before the first such fill.  (The selector reads the collection:
  * genomes, bitmap words, phams an average pair shares -- metrics.py:26-157 have one code path, this has four.) */
 int pc_last_set_kernel(const pc_ctx* ctx);
 
@@ -282,20 +283,19 @@ int pc_round6_probe(pc_ctx* ctx, const double* in, double* out, int64_t n);
  *     PC_RAW_STAGE_MAX=n        largest residue set staged through page-locked memory (512 MB; beyond: copied from the caller's pages)
  *   tuning / A-B switches (read once per process; every setting gives the same matrix, tests/ hold them to that)
  *     PC_TASK_BUDGET=n          cell slots per row stream of an alignment task (49,152)
- *     PC_CHOOSE_C0, PC_CHOOSE_C1, PC_CHOOSE_CELL   constants of the variant chooser's cost model (0.3, 0.535, 0.94)
- *     PC_REMAINDER=0, PC_REMAINDER_MARGIN=x        no narrower variant for a bucket's left-over rows / its margin (0.7)
+ *     PC_REMAINDER=0            no narrower variant for a bucket's left-over rows
  *     PC_INC16=0|1              the 11- / 10-instruction DP cell wherever both are compiled
  *     PC_SMALL_MODES=0          no one- / two-wave workgroups for tasks of few rows;  PC_SMALL_LAUNCH_MIN=n  fewest such tasks that get a launch of their own (192)
  *     PC_FUSE=0                 one launch per launch class instead of one per register tier
  *     PC_STRIP=0                column genes beyond 4,096 residues on the one-lane-per-alignment kernel instead of strip-mined passes
- *     PC_ALIGN_ORDER=size       largest class first instead of longest column genes first
  *     PC_STRIP_STREAMS=0        strip-mined launches one after the other on the caller's stream, sharing one scratch region (default: a region and a stream each)
  *     PC_SLAB_BUDGET=n          bytes the strip-mined launches' own scratch regions may take together (3 GB); what does not fit shares the first region, in line
  *     PC_LONG_PRIORITY=0        the strip-mined launches' streams at ordinary priority (default: the highest the device offers)
  *   read per fill / per launch (the tests switch them between calls)
  *     PC_POPC_TILE=32|64        force the word-split 32 x 32 / the 64 x 64 popcount tile kernel
- *     PC_SET_KERNEL=popc|sparse|sparse64|walker    force a kernel family for gcs / jc / pocp / af where it exists for the metric
+ *     PC_SET_KERNEL=popc|sparse|sparse64|sparsecol|walker    force a kernel family for gcs / jc / pocp / af where it exists for the metric
  *     PC_S64_CHUNKS=n           at least n mask chunks in the 64 x 64 sparse tile kernel
+ *     PC_COL_SEG=n              source tiles per unit of the column kernel (gcs / jc; default: by the matrix, at most 8)
  *     PC_PIPE=0|n               strip-mined launches: never pipelined (one row per wave) / always, the passes of a row over n <= 8 waves (default: by the launch's size)
  *   only in libphamclust_hip_hooks.so (compiled with -DPC_TEST_HOOKS; pc_test_hooks() == 1)
  *     PC_FAKE_OOM_ABOVE=n       device allocations above n bytes made while a fill is planning fail (fault injection)

@@ -1014,10 +1014,8 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     }
     if (launches.empty()) return PC_OK;
     // longest tasks first (a task's duration grows with its column gene's length): the tail of the fill is then made
-    // of short tasks.  PC_ALIGN_ORDER=size restores largest-class-first for A/B runs
-    static const bool by_size = getenv("PC_ALIGN_ORDER") && !strcmp(getenv("PC_ALIGN_ORDER"), "size");
+    // of short tasks
     std::stable_sort(launches.begin(), launches.end(), [&](const Launch& x, const Launch& y) {
-        if (by_size) return x.end - x.begin > y.end - y.begin;
         if (x.max_lb != y.max_lb) return x.max_lb > y.max_lb;
         return x.base != y.base ? x.base < y.base : x.mode < y.mode;
     });
@@ -1415,7 +1413,7 @@ static int fill_aligned(pc_ctx* c, int metric, int ppos, int as_distance, double
 }
 
 #ifndef PC_COL_MIN_N
-#define PC_COL_MIN_N 3000        // genomes from which k_sparse_col takes over from k_sparse_tile64 (r05 sweep: profiles/r05/experiments/sparse_col.txt)
+#define PC_COL_MIN_N 2200        // genomes from which k_sparse_col takes over from the popcount tiles (r05 sweep: profiles/r05/experiments/sparse_col.txt)
 #endif
 static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int condensed, hipStream_t st, pc_stats* stats) {
     if (!c || !c->uploaded) { pc_set_error("fill: upload first"); return PC_ERR_STATE; }
@@ -1466,10 +1464,12 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
-        // r05: gcs / jc on large matrices: the column form of the counting mode (k_sparse_col: the masks over a block of targets stay
-        // in LDS for a run of source tiles, no barrier per tile) -- while its masks fit (<= 7,680 phams with two holders)
+        // r05: gcs / jc: the column form of the counting mode (k_sparse_col: the masks over a block of targets stay in LDS for a run
+        // of source tiles, no barrier per tile) -- while its masks fit (<= 7,680 phams with two holders).  Against the popcount tiles
+        // (profiles/r05/experiments/sparse_col.txt; ms, popcount / column): 5,056 phams (79 words, 2.85 shared) N = 2,000 0.035 / 0.034,
+        // 3,000 0.070 / 0.046, 8,000 0.35 / 0.20, 20,000 2.03 / 0.99; 2,500 phams (40 words) N = 5,000 0.098 / 0.110; 1,200: 0.067 / 0.146
         const bool col_ok = counts && s64_ok && pc_sparse_col_lds(d.sp_W * 64) > 0;
-        if (kernel == K_SPARSE64 && col_ok && area >= (int64_t)PC_COL_MIN_N * PC_COL_MIN_N) kernel = K_SPARSE_COL;
+        if (col_ok && (double)d.Wb > 40.0 + 8.0 * shared && area >= (int64_t)PC_COL_MIN_N * PC_COL_MIN_N) kernel = K_SPARSE_COL;
         if (set_force) {
             if (!strcmp(set_force, "sparsecol") && col_ok) kernel = K_SPARSE_COL;
             if (!strcmp(set_force, "popc") && metric != PC_AF) kernel = K_POPC;

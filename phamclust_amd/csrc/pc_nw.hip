@@ -134,7 +134,7 @@ int pc_nw_variant_takes_any_byte(int v) { return v < 0 || v >= g_num_variants ||
 // (profiles/r01/experiments/l_variant_gcups.txt), c0 = 0.3 after the step prologue shrank to ~12 instructions (end-to-end
 // sweep: the fill time is flat within 1 % over c0 = 0.3..1.0).  The nseg term stands for what short sequences pay
 // per alignment and per task (virtual row, pipeline fill, profile build).  Minimise cost per retired row over the
-// variants whose 64*W columns cover lb.  PC_CHOOSE_C0 / PC_CHOOSE_C1 override the constants for tuning runs.
+// variants whose 64*W columns cover lb.
 // Column genes beyond the widest variant's 4,096 columns run strip-mined (k_nw_strip): ceil(lb / 64 W) passes of a wide variant,
 // a pass costing a row step of that variant per row whatever its width -- the fewest step-instructions win (W = 32 / 48 / 64:
 // 2,048 / 3,072 / 4,096 columns per pass; penalties as below).  PC_STRIP=0 sends them to the general kernel as r01-r03 did.
@@ -177,9 +177,10 @@ int pc_nw_choose_variant(int lb) {
         // measure 1.9-2.2 TCUPS at full lane use (profiles/r01/experiments/o_wide_variant_gcups.txt): one wave can keep its
         // SIMD's VALU busy, so the penalty is small
         const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
-        static const double c0 = getenv("PC_CHOOSE_C0") ? atof(getenv("PC_CHOOSE_C0")) : 0.3;
-        static const double c1 = getenv("PC_CHOOSE_C1") ? atof(getenv("PC_CHOOSE_C1")) : 0.535;
-        static const double cell = getenv("PC_CHOOSE_CELL") ? atof(getenv("PC_CHOOSE_CELL")) : 0.94;  // relative cost of the 10-instruction cell's classes (sweep 1.0 / 0.96 / 0.93 / 0.90: 239.6 / 237.8 / 238.1 / 237.9 ms at N=3,000)
+        // constants of the cost model; their sweeps came out flat (profiles/r02/experiments, r04: tools/r04 choose_sweep records) and the
+        // environment knobs that drove them (PC_CHOOSE_C0 / _C1 / _CELL) are gone (r05)
+        constexpr double c0 = 0.3, c1 = 0.535;
+        constexpr double cell = 0.94;  // relative cost of the 10-instruction cell's classes (sweep 1.0 / 0.96 / 0.93 / 0.90: 239.6 / 237.8 / 238.1 / 237.9 ms at N=3,000)
         const double cost = (W + c0 + c1 * nseg) * pen * (class_inc16(W, G) ? cell : 1.0) / nseg;
         if (best < 0 || cost < best_cost) { best = v; best_cost = cost; }
     }
@@ -193,8 +194,7 @@ int pc_nw_choose_variant(int lb) {
 int pc_nw_choose_remainder(int lb, int r, int main_variant) {
     static const bool off = getenv("PC_REMAINDER") && !strcmp(getenv("PC_REMAINDER"), "0");
     if (off || lb <= 0 || r <= 0 || main_variant < 0 || main_variant >= g_num_variants) return -1;
-    static const double c0 = getenv("PC_CHOOSE_C0") ? atof(getenv("PC_CHOOSE_C0")) : 0.3;
-    static const double c1 = getenv("PC_CHOOSE_C1") ? atof(getenv("PC_CHOOSE_C1")) : 0.535;
+    constexpr double c0 = 0.3, c1 = 0.535;
     auto step_cost = [&](int v, int& nseg) {
         const int W = g_variant_w[v], G = (lb + W - 1) / W;
         if (G > 64) { nseg = 0; return 0.0; }
@@ -204,7 +204,7 @@ int pc_nw_choose_remainder(int lb, int r, int main_variant) {
     };
     int nseg0; const double stay = step_cost(main_variant, nseg0);
     if (nseg0 <= 1 || r >= nseg0) return -1;
-    static const double margin = getenv("PC_REMAINDER_MARGIN") ? atof(getenv("PC_REMAINDER_MARGIN")) : 0.7;
+    constexpr double margin = 0.7;
     int best = -1; double best_cost = margin * stay;
     for (int v = 0; v < g_num_variants; ++v) {
         int nseg; const double sc = step_cost(v, nseg);

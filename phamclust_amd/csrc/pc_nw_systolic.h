@@ -80,9 +80,7 @@ static __constant__ int8_t c_b62[24][24] = {
 #define PCF_LAST 0x100
 #define PCF_RESET 0x200
 #define PC_MAX_SEG 16
-#ifndef PC_WIN
-#define PC_WIN 32                                   // stream entries staged per refill (32 or 64: one or two segments per 64-lane pass)
-#endif
+#define PC_WIN 32                                   // stream entries staged per refill (one segment per 64-lane pass; 64 was measured: no gain)
 
 // ---------------------------------------------------------------------------------
 // The DP cell as a LEXICOGRAPHIC MAX on 64-bit words (r02; the r01 cell carried scores and statistics in separate
@@ -134,9 +132,7 @@ __device__ __forceinline__ double pc_retag(double v, uint32_t tag) { return pc_p
 // 32-bit logic and add instructions are the ones a SIMD retires two of per 4 clocks when several waves share it
 // (profiles/valu_issue_rate.txt: ~2.2 clocks against 4.2 for v_max_f64 / SDWA / VOP3 forms; ~3.5 in the cell's mix).  Rule 0 (the
 // production rule: tags O 0, E 1, F 2): both re-tags are an OR.
-#ifndef PC_RETAG_ONE_OP
 #define PC_RETAG_ONE_OP 1
-#endif
 template <int FROM, int TO>
 __device__ __forceinline__ double pc_retag_from(double v) {
     if constexpr (PC_RETAG_ONE_OP && (FROM | TO) == TO) return pc_pack(pc_hi(v) | (uint32_t)TO, pc_lo(v));
@@ -144,23 +140,12 @@ __device__ __forceinline__ double pc_retag_from(double v) {
     else return pc_retag(v, (uint32_t)TO);
 }
 
-// PC_MAX_BUILTIN (experiment switch, off): the lexicographic maxima as the compiler's own v_max_f64 (__builtin_fmax; such builds
-// compile the alignment units with -ffinite-math-only -- tools/build_variant.py -- so that no canonicalising v_max_f64 x, x, x
-// precedes them: every value here is a positive normal double by construction) instead of inline asm.  The idea: a VALU
-// instruction that reads a register DEFINED BY INLINE ASM right after it gets an `s_nop 0` from the compiler (it must assume the
-// asm used an SDWA destination select) -- two per cell, for hazards that are not there.  MEASURED: without them the fill is 5 %
-// SLOWER (551 -> 580 ms, profiles/r04/experiments/builtin_max_ab.txt); PC_CELL_ORDER below says why.
-#ifndef PC_MAX_BUILTIN
-#define PC_MAX_BUILTIN 0
-#endif
-__device__ __forceinline__ double pc_max64(double a, double b) { return __builtin_fmax(a, b); }
-
 // One cell.  In: D (this cell's diagonal candidate, tag 3), chain values HoL [tag tOF] and EL [tE], row code ac.
 // In/out (in place): column state Hou -> Ho, Fu -> F.  Out: E (chain), and for the next cell Dn = old Hou + score of the
 // next cell (+ 3 - tOF, folded into the profile byte) with statistics old Hou's + 0x10000 + (ac == bcn).
 // The first block is asm because of its SDWA forms and because v_cmp's SGPR result must not be read by v_addc sooner than
 // two instructions later (gfx950; nothing pads inside asm): the two independent v_max_f64 sit in between.
-template <int NEXT_COL, int RULE, bool INC16, bool U8 = false>
+template <int NEXT_COL, int RULE, bool INC16>
 __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, double& Hou, double& Fu, double& E, double& Dn,
                                           uint32_t ac, uint32_t bcn, uint32_t pwn, uint32_t pmn, uint32_t K) {
     using T = PcTag<RULE>;
@@ -168,20 +153,8 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
     if constexpr (T::cyclic) HoL = pc_pack(pc_hi(HoL) + (uint32_t)(T::tOE - T::tOF), pc_lo(HoL));
     const uint32_t ohi = pc_hi(Hou), olo = pc_lo(Hou);
     uint32_t dn_hi = 0, dn_lo = 0;
-    if constexpr (NEXT_COL < 0 && PC_MAX_BUILTIN) {
-        E = pc_max64(HoL, EL);
-        Fu = pc_max64(Hou, Fu);
-    } else if constexpr (NEXT_COL < 0) {
+    if constexpr (NEXT_COL < 0) {
         asm("v_max_f64 %[E], %[HoL], %[EL]\n\tv_max_f64 %[Fu], %[Hou], %[Fu]" : [E] "=&v"(E), [Fu] "+v"(Fu) : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou));
-    } else if constexpr (INC16 && U8) {
-        // PC_PROF_U8: the LDS did the byte / word select (ds_read_u8, ds_read_u16): `pwn` IS the next column's score entry, `pmn` its
-        // statistics increment, and both adds are plain VOP2 -- the fast issue class (see pc_retag_from)
-        asm("v_max_f64 %[E], %[HoL], %[EL]\n\t"
-            "v_max_f64 %[Fu], %[Hou], %[Fu]\n\t"
-            "v_add_u32 %[dh], %[pwn], %[ohi]\n\t"
-            "v_add_u32 %[dl], %[pmn], %[olo]"
-            : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo)
-            : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn));
     } else if constexpr (INC16) {
         // the statistics' increment comes from the profile too: a 16-bit entry 0x2000 + (row residue == column residue)
 #define PC_CELL64_B(SEL, WSEL)                                                                                         \
@@ -191,23 +164,11 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
         "v_add_u32_sdwa %[dl], %[pmn], %[olo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" WSEL " src1_sel:DWORD"    \
         : [E] "=&v"(E), [Fu] "+v"(Fu), [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo)                                            \
         : [HoL] "v"(HoL), [EL] "v"(EL), [Hou] "v"(Hou), [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn))
-#define PC_CELL64_ADDS(SEL, WSEL)                                                                                      \
-    asm("v_add_u32_sdwa %[dh], %[pwn], %[ohi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t" \
-        "v_add_u32_sdwa %[dl], %[pmn], %[olo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" WSEL " src1_sel:DWORD"    \
-        : [dh] "=&v"(dn_hi), [dl] "=&v"(dn_lo) : [ohi] "v"(ohi), [olo] "v"(olo), [pwn] "v"(pwn), [pmn] "v"(pmn))
-        if constexpr (PC_MAX_BUILTIN) {
-            if constexpr (NEXT_BYTE == 0) PC_CELL64_ADDS("BYTE_0", "WORD_0");
-            else if constexpr (NEXT_BYTE == 1) PC_CELL64_ADDS("BYTE_1", "WORD_1");
-            else if constexpr (NEXT_BYTE == 2) PC_CELL64_ADDS("BYTE_2", "WORD_0");
-            else PC_CELL64_ADDS("BYTE_3", "WORD_1");
-            E = pc_max64(HoL, EL);
-            Fu = pc_max64(Hou, Fu);
-        } else if constexpr (NEXT_BYTE == 0) PC_CELL64_B("BYTE_0", "WORD_0");
+        if constexpr (NEXT_BYTE == 0) PC_CELL64_B("BYTE_0", "WORD_0");
         else if constexpr (NEXT_BYTE == 1) PC_CELL64_B("BYTE_1", "WORD_1");
         else if constexpr (NEXT_BYTE == 2) PC_CELL64_B("BYTE_2", "WORD_0");
         else PC_CELL64_B("BYTE_3", "WORD_1");
 #undef PC_CELL64_B
-#undef PC_CELL64_ADDS
     } else {
         unsigned long long c2;
 #define PC_CELL64_A(SEL)                                                                                               \
@@ -228,8 +189,7 @@ __device__ __forceinline__ void pc_cell64(double D, double HoL, double EL, doubl
     E = pc_retag_from<T::tOE, T::tE>(E);             // E came from HoL [tOE] or EL [tE]
     Fu = pc_retag_from<T::tOF, T::tF>(Fu);           // F from Hou [tOF] or Fu [tF]
     double H;
-    if constexpr (PC_MAX_BUILTIN) H = pc_max64(pc_max64(D, Fu), E);
-    else asm("v_max_f64 %0, %1, %2\n\tv_max_f64 %0, %0, %3" : "=&v"(H) : "v"(D), "v"(Fu), "v"(E));
+    asm("v_max_f64 %0, %1, %2\n\tv_max_f64 %0, %0, %3" : "=&v"(H) : "v"(D), "v"(Fu), "v"(E));
     Hou = pc_pack((pc_hi(H) & ~3u) + (uint32_t)(T::tOF - 40), pc_lo(H));
     Dn = pc_pack(dn_hi, dn_lo);
 }
@@ -267,161 +227,6 @@ struct PcRow {          // compile-time unrolled sweep over the lane's W columns
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C + 1 < W) PcRow<W, C + 1, RULE, INC16>::run(Dn, Hou[C], E, Hou, Fu, bc, pw, pm, nxt, ac, K, E_out);
-        else E_out = E;
-    }
-};
-
-// PC_CELL_ORDER (r04, experiment harness): the profile cell's sweep with the maxima as compiler instructions and the ORDER of the ten
-// instructions pinned from the source (a scheduling barrier after each), to find out what the hand-placed asm blocks of pc_cell64 owe
-// to their order and what to the two `s_nop 0` the compiler puts behind them (the plain builtin form -- same instructions, no
-// s_nop, compiler's order -- is 5 % SLOWER: profiles/r04/experiments/builtin_max_ab.txt).
-//   1: pc_cell64's order, no s_nop      2: pc_cell64's order with its two s_nop 0
-//   3: software-pipelined -- the next cell's independent work (its F maximum, its diagonal-term adds) between the links of the
-//      dependent chain E -> re-tag -> H -> Ho, no s_nop      4: the same with an s_nop 0 ahead of the Ho fix-up
-//   5-9: pc_cell64's order with s_nop 0 at other sets of positions (see PcRowS::run)
-// MEASURED (profiles/r04/experiments/cell_order_and_nops_ab.txt; N = 2,000 fill, alignment ms): asm blocks (= order 2) 117.4 | 1: 123.2 |
-// 2: 118.7 | 3: 122.8 | 4: 119.2 | 5: 119.6 | 6: 121.7 | 7: 119.8 | 8: 118.3 | 9: 120.7.  The ORDER is worth nothing (1 = 3, 2 = 4): what
-// the asm blocks owe their 4.5 % to is the compiler's two s_nop 0 -- a pause of the WAVE ahead of a 32-bit instruction that reads a
-// v_max_f64 result (an independent VALU instruction in the same place does not do it: 3), and more pauses only cost (5, 6, 7).
-// Longer pauses ahead of the cheap runs (10 / 11 / 12: s_nop 1 / 3 / 7) only cost: 122.0 / 124.9 / 137.8.
-// So the product stays on pc_cell64's asm blocks; this harness is compiled out.
-#ifndef PC_CELL_ORDER
-#define PC_CELL_ORDER 0
-#endif
-#define PC_SB() __builtin_amdgcn_sched_barrier(0)
-template <int N>
-__device__ __forceinline__ uint32_t pc_dn_hi(uint32_t pw, uint32_t ohi) {        // hi of column N's diagonal term: old Ho of column N - 1 + score byte
-    uint32_t d;
-    if constexpr ((N & 3) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
-    else if constexpr ((N & 3) == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
-    else if constexpr ((N & 3) == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
-    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(d) : "v"(pw), "v"(ohi));
-    return d;
-}
-template <int N>
-__device__ __forceinline__ uint32_t pc_dn_lo(uint32_t pm, uint32_t olo) {        // lo: its statistics + the 16-bit increment
-    uint32_t d;
-    if constexpr ((N & 1) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(d) : "v"(pm), "v"(olo));
-    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(d) : "v"(pm), "v"(olo));
-    return d;
-}
-template <int W, int C, int RULE, int ORD>
-struct PcRowS {
-    static constexpr int ND = (W + 3) / 4, NDM = (W + 1) / 2;
-    using T = PcTag<RULE>;
-    template <int N>
-    static __device__ __forceinline__ void reload(uint32_t (&pw)[ND], uint32_t (&pm)[NDM], pc_lds_u32* nxt) {   // column N's operands have been read
-        if constexpr (N >= 0 && N < W && ((N & 1) || N == W - 1)) {
-            if constexpr ((N & 3) == 3 || N == W - 1) pw[N >> 2] = nxt[(N >> 2) * 64];
-            pm[N >> 1] = nxt[(ND + (N >> 1)) * 64];
-            PC_SB();
-        }
-    }
-    // what cell 0 needs before the pipelined sweep starts: its F maximum and column 1's diagonal term
-    static __device__ __forceinline__ void start(double (&Hou)[W], double (&Fu)[W], uint32_t (&pw)[ND], uint32_t (&pm)[NDM], pc_lds_u32* nxt,
-                                                 double& Fm, uint32_t& dnh, uint32_t& dnl) {
-        PC_SB();
-        Fm = pc_max64(Hou[0], Fu[0]); PC_SB();
-        dnh = 0; dnl = 0;
-        if constexpr (W > 1) { dnh = pc_dn_hi<1>(pw[0], pc_hi(Hou[0])); PC_SB(); dnl = pc_dn_lo<1>(pm[0], pc_lo(Hou[0])); PC_SB(); reload<1>(pw, pm, nxt); }
-    }
-    static __device__ __forceinline__ void run(double D, double HoL, double EL, double Fm, uint32_t dnh, uint32_t dnl, double (&Hou)[W], double (&Fu)[W],
-                                               uint32_t (&pw)[ND], uint32_t (&pm)[NDM], pc_lds_u32* nxt, double& E_out) {
-        constexpr bool HAS1 = C + 1 < W, HAS2 = C + 2 < W;
-        if constexpr (T::cyclic) HoL = pc_pack(pc_hi(HoL) + (uint32_t)(T::tOE - T::tOF), pc_lo(HoL));
-        double E, H, Fm2 = 0.0; uint32_t dnh2 = 0, dnl2 = 0;
-        if constexpr (ORD <= 2 || ORD >= 5) {
-            // pc_cell64's order; s_nop 0 at the positions the order number names: P0 ahead of the E maximum (i.e. behind the previous
-            // cell's Ho), P1 ahead of the re-tags, P2 / P3 ahead of the two H maxima, P4 ahead of the Ho fix-up, P5 inside it
-            constexpr bool P0 = ORD == 5 || ORD == 6 || ORD == 7, P1 = ORD == 2 || ORD == 5 || ORD == 6 || ORD == 8 || ORD >= 10, P2 = ORD == 6, P3 = ORD == 6,
-                           P4 = ORD == 2 || ORD >= 5, P5 = ORD == 6;
-            // 10 / 11 / 12: longer pauses ahead of the two runs of cheap instructions (s_nop 1 / 3 / 7 at P1 and P4): a cheap instruction
-            // rides the second VALU pipe only beside another wave's (valu2_share.txt) -- does waiting longer find it a partner?
-#define PC_PAUSE_LONG() do { if constexpr (ORD == 10) asm volatile("s_nop 1"); else if constexpr (ORD == 11) asm volatile("s_nop 3"); else asm volatile("s_nop 7"); } while (0)
-            if constexpr (P0) { asm volatile("s_nop 0"); PC_SB(); }
-            E = pc_max64(HoL, EL); PC_SB();
-            Fm = pc_max64(Hou[C], Fu[C]); PC_SB();
-            if constexpr (HAS1) { dnh = pc_dn_hi<C + 1>(pw[(C + 1) >> 2], pc_hi(Hou[C])); PC_SB(); dnl = pc_dn_lo<C + 1>(pm[(C + 1) >> 1], pc_lo(Hou[C])); PC_SB(); }
-            if constexpr (P1) { if constexpr (ORD >= 10) PC_PAUSE_LONG(); else asm volatile("s_nop 0"); PC_SB(); }
-            E = pc_retag_from<T::tOE, T::tE>(E); PC_SB();
-            Fm = pc_retag_from<T::tOF, T::tF>(Fm); PC_SB();
-            if constexpr (P2) { asm volatile("s_nop 0"); PC_SB(); }
-            H = pc_max64(D, Fm); PC_SB();
-            if constexpr (P3) { asm volatile("s_nop 0"); PC_SB(); }
-            H = pc_max64(H, E); PC_SB();
-            if constexpr (P4) { if constexpr (ORD >= 10) PC_PAUSE_LONG(); else if constexpr (ORD == 8) asm volatile("s_nop 1"); else asm volatile("s_nop 0"); PC_SB(); }
-            const uint32_t t = pc_hi(H) & ~3u; PC_SB();
-            if constexpr (P5) { asm volatile("s_nop 0"); PC_SB(); }
-            Hou[C] = pc_pack(t + (uint32_t)(T::tOF - 40), pc_lo(H)); PC_SB();
-            Fu[C] = Fm;
-            reload<C + 1>(pw, pm, nxt);
-        } else {
-            E = pc_max64(HoL, EL); PC_SB();
-            Fm = pc_retag_from<T::tOF, T::tF>(Fm); PC_SB();
-            if constexpr (HAS2) { dnl2 = pc_dn_lo<C + 2>(pm[(C + 2) >> 1], pc_lo(Hou[C + 1])); PC_SB(); }
-            E = pc_retag_from<T::tOE, T::tE>(E); PC_SB();
-            H = pc_max64(D, Fm); PC_SB();
-            if constexpr (HAS1) { Fm2 = pc_max64(Hou[C + 1], Fu[C + 1]); PC_SB(); }
-            H = pc_max64(H, E); PC_SB();
-            if constexpr (HAS2) { dnh2 = pc_dn_hi<C + 2>(pw[(C + 2) >> 2], pc_hi(Hou[C + 1])); PC_SB(); }
-            if constexpr (ORD == 4) { asm volatile("s_nop 0"); PC_SB(); }
-            const uint32_t t = pc_hi(H) & ~3u; PC_SB();
-            Hou[C] = pc_pack(t + (uint32_t)(T::tOF - 40), pc_lo(H)); PC_SB();
-            Fu[C] = Fm;
-            if constexpr (HAS2) reload<C + 2>(pw, pm, nxt);
-        }
-        if constexpr (HAS1) PcRowS<W, C + 1, RULE, ORD>::run(pc_pack(dnh, dnl), Hou[C], E, Fm2, dnh2, dnl2, Hou, Fu, pw, pm, nxt, E_out);
-        else E_out = E;
-    }
-};
-
-// PC_PROF_U8 (r04): the profile cell's operands read from LDS one COLUMN at a time -- ds_read_u8 of the score byte, ds_read_u16 of
-// the increment, same table, same addresses -- so that the two adds of a cell are plain VOP2 instead of SDWA (the fast issue class:
-// see pc_retag_from).  Entry m of a row (m = 0: the step prologue's, m >= 1: cell m - 1's "next column") lives in one of TWO slots,
-// (m + W x step parity) & 1, and a slot is re-loaded right after the instruction that read it with the entry two further on -- of
-// this row, or, for a row's last two, of the next row (`nxt`): every load is two cells ahead of its use, and 4 registers replace
-// W/4 + W/2.  The slots are 32-bit: a narrower operand cannot be a "v" operand, and the compiler masks (v_and_b32 0xff / 0xffff)
-// only what crosses a branch or the loop's back edge -- the four entries in flight at a step boundary (a slot per entry, as a
-// first version had it, crossed with ten).
-// MEASURED AND NOT TAKEN (profiles/r04/experiments/profile_u8_reads_ab.txt): bit-exact, 6-18 registers fewer, and SLOWER --
-// synth(5000,5000) peq 550 -> 559 ms, N = 2,000 117.5 -> 120.5; uniform 420-residue genes (8-wave workgroups) 3,172 -> 2,692 GCUPS:
-// two LDS instructions per cell (against 0.75) cost more at the LDS than the two SDWA adds cost at the VALU.  Kept compiled out.
-#ifndef PC_PROF_U8
-#define PC_PROF_U8 0
-#endif
-typedef __attribute__((address_space(3))) const uint8_t pc_lds_u8;
-typedef __attribute__((address_space(3))) const uint16_t pc_lds_u16;
-template <int W>
-struct PcU8 {
-    static constexpr int ND = (W + 3) / 4;
-    static __host__ __device__ constexpr int slot(int m, int par) { return (m + par * W) & 1; }
-    static __device__ __forceinline__ uint32_t score(uint32_t row, int m) { return (uint32_t)*(pc_lds_u8*)(size_t)(row + (uint32_t)((m >> 2) * 256 + (m & 3))); }
-    static __device__ __forceinline__ uint32_t incr(uint32_t row, int m) { return (uint32_t)*(pc_lds_u16*)(size_t)(row + (uint32_t)((ND + (m >> 1)) * 256 + (m & 1) * 2)); }
-    // entry M of a row of parity PAR has just been read: what its slot holds next
-    template <int M, int PAR>
-    static __device__ __forceinline__ void reload(uint32_t (&sc)[2], uint32_t (&in)[2], uint32_t cur, uint32_t nxt) {
-        constexpr int S = slot(M, PAR);
-        if constexpr (M + 2 <= W - 1) { sc[S] = score(cur, M + 2); in[S] = incr(cur, M + 2); }
-        else { sc[S] = score(nxt, M + 2 - W); in[S] = incr(nxt, M + 2 - W); static_assert(slot(M + 2 - W, PAR ^ 1) == S, "slot parity"); }
-    }
-    static __device__ __forceinline__ void first(uint32_t (&sc)[2], uint32_t (&in)[2], uint32_t row) {      // row of parity 0
-        sc[0] = score(row, 0); in[0] = incr(row, 0); sc[1] = score(row, 1); in[1] = incr(row, 1);
-    }
-};
-template <int W, int C, int RULE, int PAR>
-struct PcRowU8 {
-    using U = PcU8<W>;
-    static __device__ __forceinline__ void run(double D, double HoL, double EL, double (&Hou)[W], double (&Fu)[W],
-                                               uint32_t (&sc)[2], uint32_t (&in)[2], uint32_t cur, uint32_t nxt, double& E_out) {
-        double E, Dn;
-        constexpr int N = (C + 1 < W) ? C + 1 : -1;
-        pc_cell64<N, RULE, true, true>(D, HoL, EL, Hou[C], Fu[C], E, Dn, 0u, 0u, sc[N < 0 ? 0 : U::slot(N, PAR)], in[N < 0 ? 0 : U::slot(N, PAR)], 0u);
-        if constexpr (N >= 0) {
-            __builtin_amdgcn_sched_barrier(0);           // load here, into the registers that have just died
-            U::template reload<N, PAR>(sc, in, cur, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (C + 1 < W) PcRowU8<W, C + 1, RULE, PAR>::run(Dn, Hou[C], E, Hou, Fu, sc, in, cur, nxt, E_out);
         else E_out = E;
     }
 };
@@ -648,14 +453,8 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
     uint32_t a = is_head ? ring[ring_lane] : 0u;
     uint32_t e_nxt = ring[ring_lane + 1];                          // head's entry for step 1 (PC_WIN >= 2)
     uint32_t e_b = 0;                                              // entry t+3 (entries t+2, t+3 are fetched as a pair on even steps)
-    constexpr bool U8 = INC16 && PC_PROF_U8;                       // profile operands by ds_read_u8 / _u16, one column at a time (PcRowU8)
-    uint32_t pw[U8 ? 1 : ND], pm[(INC16 && !U8) ? NDM : 1];        // this row's score bytes and statistics increments
-    uint32_t u_sc[2], u_in[2], u_cur = 0;   // U8: the entries in flight, and this row's strip address
-    if constexpr (U8) {
-        u_cur = row_addr(a);
-        PcU8<W>::first(u_sc, u_in, u_cur);
-        pw[0] = 0; pm[0] = 0;
-    } else {
+    uint32_t pw[ND], pm[INC16 ? NDM : 1];                          // this row's score bytes and statistics increments
+    {
         pc_lds_u32* r0 = (pc_lds_u32*)(size_t)row_addr(a);
 #pragma unroll
         for (int q = 0; q < ND; ++q) pw[q] = r0[q * 64];
@@ -673,7 +472,6 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
     // One row step.  `a` is this step's stream entry, `a_nxt` receives the next step's.
     auto step = [&](int t, auto even_tag, uint32_t a, uint32_t& a_nxt) {
         constexpr bool even = decltype(even_tag)::value;
-        constexpr int PAR = even ? 0 : 1;                                 // row parity (U8 slot assignment)
         if (even && ((t + 2) & (PC_WIN - 1)) == 0) refill(t + 2);
         // Step prologue, 9 VALU instructions.  The five neighbour exchanges are v_cndmask_b32_dpp: lane k takes lane
         // k-1's value (DPP wave_shr:1 on src0, executed with every lane active), head lanes (vcc) take src1 = their
@@ -683,26 +481,7 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
         // K.BYTE_2 == 1.
         uint32_t HoL_hi, HoL_lo, EL_hi, EL_lo, D0_hi, D0_lo;
         unsigned long long anym;
-        if constexpr (U8) {
-            asm volatile(
-                "s_nop 1\n\t"
-                "s_mov_b64 vcc, %[hm]\n\t"
-                "v_cndmask_b32_dpp %[an], %[a], %[en], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cndmask_b32_dpp %[Hh], %[Hwh], %[hb], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cndmask_b32_dpp %[Eh], %[oEh], %[neg], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cndmask_b32_dpp %[Hl], %[Hwl], %[zero], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_mov_b32_dpp %[El], %[oEl] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cmp_ne_u32_sdwa %[anym], %[a], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-                "v_add_u32 %[D0h], %[pw0], %[Hodh]\n\t"                     // column 0's entries are whole dwords here
-                "v_add_u32 %[D0l], %[pm0], %[Hodl]\n\t"
-                "s_and_b64 %[anym], %[anym], %[hom]\n\t"
-                : [an] "=&v"(a_nxt), [Hh] "=&v"(HoL_hi), [Eh] "=&v"(EL_hi), [Hl] "=&v"(HoL_lo), [El] "=&v"(EL_lo), [D0h] "=&v"(D0_hi),
-                  [D0l] "=&v"(D0_lo), [anym] "=&s"(anym)
-                : [hm] "s"(headm), [hom] "s"(headoutm), [a] "v"(a), [en] "v"(e_nxt), [Hwh] "v"(pc_hi(Hou[W - 1])), [hb] "v"(v_hb), [oEh] "v"(pc_hi(o_E)), [neg] "v"(v_nege),
-                  [Hwl] "v"(pc_lo(Hou[W - 1])), [zero] "v"(v_zero), [oEl] "v"(pc_lo(o_E)), [pw0] "v"(u_sc[PcU8<W>::slot(0, PAR)]), [pm0] "v"(u_in[PcU8<W>::slot(0, PAR)]),
-                  [Hodh] "v"(pc_hi(p_HoL)), [Hodl] "v"(pc_lo(p_HoL))
-                : "vcc", "scc");
-        } else if constexpr (INC16) {
+        if constexpr (INC16) {
             asm volatile(
                 "s_nop 1\n\t"                                               // VALU (previous step's cells) -> DPP read: 2 wait states
                 "s_mov_b64 vcc, %[hm]\n\t"
@@ -745,11 +524,6 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
         }
         const uint32_t nxt_addr = row_addr(a_nxt);                        // the next row's strip
         pc_lds_u32* nxt = (pc_lds_u32*)(size_t)nxt_addr;
-        if constexpr (U8) {
-            __builtin_amdgcn_sched_barrier(0);
-            PcU8<W>::template reload<0, PAR>(u_sc, u_in, u_cur, nxt_addr);   // the prologue has read entry 0
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (even) {                                                       // the head's entries for steps t+2 and t+3
             const uint2 e2 = *(const uint2*)&ring[ring_lane + ((t + 2) & (PC_WIN - 1))];
             e_nxt = e2.x; e_b = e2.y;
@@ -774,14 +548,7 @@ __device__ __forceinline__ void pc_nw_body(const PcDev& d, const PcTask* __restr
         }
         const double HoL = pc_pack(HoL_hi, HoL_lo);
         p_HoL = HoL;
-        if constexpr (U8) {
-            PcRowU8<W, 0, RULE, PAR>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, u_sc, u_in, u_cur, nxt_addr, o_E);
-            u_cur = nxt_addr;
-        } else if constexpr (INC16 && PC_CELL_ORDER > 0) {
-            double Fm = 0.0; uint32_t dnh = 0, dnl = 0;
-            if constexpr (PC_CELL_ORDER == 3 || PC_CELL_ORDER == 4) PcRowS<W, 0, RULE, PC_CELL_ORDER>::start(Hou, Fu, pw, pm, nxt, Fm, dnh, dnl);
-            PcRowS<W, 0, RULE, PC_CELL_ORDER>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Fm, dnh, dnl, Hou, Fu, pw, pm, nxt, o_E);
-        } else PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
+        PcRow<W, 0, RULE, INC16>::run(pc_pack(D0_hi, D0_lo), HoL, pc_pack(EL_hi, EL_lo), Hou, Fu, bc, pw, pm, nxt, a, K, o_E);
         asm volatile("" : "+s"(lastm));                                   // test here, not 140 instructions earlier (the compiler would carry the result as a lane mask: one VALU compare)
         if (lastm != 0) {                                                 // a row's last cell left the lane holding column lb-1
             asm volatile("" ::: "memory");                                // keep this wave-uniform (scalar) test a branch of its own

@@ -990,12 +990,12 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 // Needs 8 B x phams-with-two-holders of LDS beside the accumulators: up to 7,680 such phams; beyond, or for small matrices, the
 // kernels above run.  No MFMA: this is a sparse join, ~3 shared phams per pair.
 // ---------------------------------------------------------------------------------
-#define S7_SEG 8                                                  // source tiles per unit
+#define S7_SEG 8                                                  // source tiles per unit, at most (small matrices: fewer, see the launcher)
 #define S7_B 2                                                    // 64-entry batches of a row held in registers (a row's ~100 entries)
 #define S7_WAVES 16
 #define S7_RPW (S6_T / S7_WAVES)                                  // rows (of either side) a wave owns
 template <int MODE>
-__global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int P64, int nty) {
+__global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int P64, int nty, int seg) {
     static_assert(MODE == S6_GCS || MODE == S6_JC, "counting modes only");
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
     uint32_t* colmask = sp_lds;                                                    // [P64][2]: which of the block's 64 targets hold the pham
@@ -1009,9 +1009,9 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
     const int k0 = ty * S6_T;
     const int klast = min(k0 + S6_T, sh.nown) - 1;
     const int live = (pc_owned(sh, klast) + S6_T - 1) / S6_T;                      // source tiles with a pair s < t in them: s0 < the block's last target
-    const int tx1 = live - run * S7_SEG;
+    const int tx1 = live - run * seg;
     if (tx1 <= 0) return;
-    const int tx0 = max(0, tx1 - S7_SEG);
+    const int tx0 = max(0, tx1 - seg);
 
     // ---- once per unit: the masks over the targets
     const int gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;           // lane l <-> target row l, for the whole unit
@@ -1146,10 +1146,16 @@ int pc_launch_sparse_col(int mode, const PcDev& d, const PcShard& sh, double* ou
     const size_t lds = pc_sparse_col_lds(P64);
     if (!lds || (mode != S6_GCS && mode != S6_JC)) { pc_set_error("k_sparse_col: mode %d, %d mask entries", mode, P64); return PC_ERR_LIMIT; }
     const int nty = (sh.nown + S6_T - 1) / S6_T, ntx = (d.N + S6_T - 1) / S6_T;
-    const unsigned runs = (unsigned)((ntx + S7_SEG - 1) / S7_SEG);
+    // source tiles per unit: as many as leave ~2 units per workgroup slot of the chip (2 slots per CU), at most S7_SEG.  Measured, jc, ms
+    // (profiles/r05/experiments/sparse_col.txt): N = 2,000 / 3,000 / 5,000 / 20,000 with 1 tile per unit 0.034 / 0.046 / 0.105 / 1.27,
+    // 2: 0.047 / 0.049 / 0.092 / 1.10, 4: 0.058 / 0.060 / 0.093 / 1.02, 8: 0.081 / 0.083 / 0.100 / 0.99, 16: 0.126 / 0.127 / 0.166 / 1.005
+    const int64_t live_tiles = (int64_t)nty * ntx / 2 + nty;
+    int seg = (int)std::max<int64_t>(1, std::min<int64_t>(S7_SEG, live_tiles / (4 * (int64_t)(d.n_cu > 0 ? d.n_cu : 256))));
+    if (const char* force = getenv("PC_COL_SEG")) { const int v = atoi(force); if (v >= 1 && v <= 64) seg = v; }
+    const unsigned runs = (unsigned)((ntx + seg - 1) / seg);
     dim3 grid(((unsigned)nty + 7u) / 8u * 8u * runs), block(64 * S7_WAVES);
-    if (mode == S6_GCS) hipLaunchKernelGGL((k_sparse_col<S6_GCS>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty);
-    else hipLaunchKernelGGL((k_sparse_col<S6_JC>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty);
+    if (mode == S6_GCS) hipLaunchKernelGGL((k_sparse_col<S6_GCS>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
+    else hipLaunchKernelGGL((k_sparse_col<S6_JC>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_col launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;

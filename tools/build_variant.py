@@ -29,8 +29,6 @@ def main(name, flags):
             objs.append(os.path.join(b.CSRC, obj_name))
             continue
         obj = os.path.join(out_dir, obj_name)
-        if src.startswith("pc_nw") and any(f.startswith(("-DPC_MAX_BUILTIN", "-DPC_CELL_ORDER")) for f in flags):
-            extra = extra + ["-ffinite-math-only"]          # __builtin_fmax without canonicalising v_max_f64 x, x, x (pc_nw_systolic.h)
         cmd = [hipcc] + b.HIPCC_FLAGS + ["-cuid=" + os.path.splitext(obj_name)[0]] + extra + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj]
         jobs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)

@@ -2,6 +2,13 @@
 """Condense rocprofv3 CSV output (kernel trace / stats / PMC passes) into one small JSON for profiles/.
 
 usage: summarize_profile.py --trace DIR [--fetch DIR] [--write DIR] --fills N --out FILE
+       summarize_profile.py k4span TRACE_DIR OUT.txt [BENCH.json]
+
+k4span: the K4 (alignment) launches of every fill in a rocprofv3 --kernel-trace of `bench.py` -- launches, first start -> last end
+(the SPAN: what bench.py's HIP events around the alignment stage see, `roofline.ms_kernels_per_fill`), and the SUM of the launches'
+own durations (they overlap on several streams, so the sum is 2-3 x the span: it is what --stats' per-kernel totals add up to, and
+NOT the time the roofline divides by).  With the bench line: DP cells / span = TCUPS, against the 4.915-TCUPS VALU ceiling.  The
+text file goes to profiles/<round>/final/bench_peq5000_k4_span.txt, so that `frac` can be redone from tracked files alone.
 """
 import argparse
 import collections
@@ -13,6 +20,65 @@ import json
 def one(d, pat):
     f = glob.glob(f"{d}/**/*{pat}", recursive=True)
     return f[0] if f else None
+
+
+def k4_fills(trace_dir):
+    """[(first start ns, last end ns, launches, summed ns, {kernel: summed ns})] per fill: K4 launches grouped by gaps > 1 ms."""
+    rows = list(csv.DictReader(open(one(trace_dir, "_kernel_trace.csv"))))
+    nw = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")) for r in rows if "k_nw" in r["Kernel_Name"])
+    fills, cur = [], None
+    for s, e, name in nw:
+        if cur is None or s > cur[1] + 1_000_000:
+            if cur is not None:
+                fills.append(cur)
+            cur = [s, e, 0, 0, collections.defaultdict(int)]
+        cur[1] = max(cur[1], e); cur[2] += 1; cur[3] += e - s; cur[4][name] += e - s
+    if cur is not None:
+        fills.append(cur)
+    return fills
+
+
+def k4span(trace_dir, out_path, bench_path=None):
+    import sys
+    fills = k4_fills(trace_dir)
+    line = None
+    if bench_path:
+        line = json.loads([l for l in open(bench_path).read().splitlines() if l.startswith("{")][-1])
+    lines = [f"# K4 (k_nw_*) launches per fill in the rocprofv3 kernel trace under {trace_dir} (tools/summarize_profile.py k4span)",
+             "# span = first K4 start -> last K4 end of a fill: the time `roofline` divides by; sum = the launches' own durations added up (they overlap on",
+             "# several streams): what the per-kernel totals of *_kernel_stats.csv add up to", f"{'fill':>4s} {'launches':>8s} {'span_ms':>10s} {'sum_ms':>10s} {'sum/span':>8s}"]
+    for k, (s, e, n, tot, per) in enumerate(fills):
+        lines.append(f"{k:4d} {n:8d} {(e - s) / 1e6:10.3f} {tot / 1e6:10.3f} {tot / max(e - s, 1):8.2f}")
+    spans = [(e - s) / 1e6 for s, e, *_ in fills]
+    if line and line.get("kernel_source_hash"):
+        lines.insert(1, f"# device code of the traced library (bench.py kernel_source_hash): {line['kernel_source_hash']}")
+    if spans:
+        steady = spans[1:] if len(spans) > 1 else spans          # the first fill of a process pays code-object loads
+        mean = sum(steady) / len(steady)
+        lines.append(f"span, mean over fills 1..{len(spans) - 1}: {mean:.3f} ms (min {min(steady):.3f}, max {max(steady):.3f}); first fill {spans[0]:.3f} ms")
+        if line and "roofline" in line and "dp_cells_computed" in line["roofline"]:
+            cells = line["roofline"]["dp_cells_computed"]
+            peak = line["roofline"]["peak_gcups"]
+            lines.append(f"DP cells computed per fill (bench line): {cells} -> {cells / mean / 1e9:.4f} TCUPS over the traced span = {cells / mean / 1e6 / peak:.4f} of the "
+                         f"{peak / 1e3:.3f}-TCUPS VALU ceiling; the bench line's own HIP-event figure (no profiler attached): ms_kernels_per_fill "
+                         f"{line['roofline']['ms_kernels_per_fill']:.3f} ms, frac {line['roofline']['frac']:.4f}")
+        per = collections.defaultdict(int)
+        for *_, p in fills[1:] if len(fills) > 1 else fills:
+            for name, v in p.items():
+                per[name] += v
+        nf = max(len(fills) - 1, 1)
+        lines.append("# summed duration per kernel and fill (ms), fills 1..:")
+        for name, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]:
+            lines.append(f"{v / 1e6 / nf:10.3f}  {name}")
+    text = "\n".join(lines) + "\n"
+    open(out_path, "w").write(text)
+    sys.stdout.write(text)
+
+
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] == "k4span":
+    k4span(_sys.argv[2], _sys.argv[3], _sys.argv[4] if len(_sys.argv) > 4 else None)
+    raise SystemExit(0)
 
 
 ap = argparse.ArgumentParser()
