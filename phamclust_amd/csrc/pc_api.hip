@@ -142,6 +142,7 @@ struct pc_ctx {
     int64_t n_residue_bytes_in = 0;         // residue bytes of the packed genomes part 1 saw (part 2 must be given the same)
     PcDev dev{};
     std::vector<int32_t> h_gene_len;
+    std::vector<uint32_t> h_para_off;                  // [N+1] host copy of the paralog-entry offsets (k_sparse_col's pocp mode: entries per block of targets)
     std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
     int max_gene_len = 0, min_gene_len = 0, max_nph = 0, max_ngen = 0;
     int64_t max_tlen = 0;                    // largest summed translation length of a genome
@@ -406,6 +407,9 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
     if ((rc = wait_last_work(c, nullptr, false))) return rc;
     c->uploaded = false; c->residues_ready = false; c->target_cost.clear(); c->plan.valid = false;
     PC_HIP(hipStreamSynchronize(c->stream));
+    // a new collection: a slab of scratch the last one's long genes needed (up to 4 GB: run_align_classes) is not kept for it
+    // (grow-only inside a collection; nothing of the context is in flight here)
+    if (c->b_scratch.cap > ((size_t)512 << 20)) c->b_scratch.release();
 
     // ---- host-side indices, written straight into ONE page-locked staging buffer the context keeps (grow-only) and sent with
     // ONE copy (eleven pageable copies were 1.2 of the 1.9 ms of this stage at N = 2,000).  Several threads: genomes are
@@ -534,6 +538,7 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         }
         para_off[N] = (uint32_t)at;
         c->max_ngen = max_ngen;
+        c->h_para_off.assign(para_off, para_off + N + 1);
     }
     // The 64 x 64 sparse tile kernel's own lists: only phams that at least TWO genomes hold (nothing else can be shared; in real
     // collections about half of all phams have one holder), renumbered densely in pham order, each entry as (dense id, value) pairs
@@ -1032,25 +1037,37 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
     std::vector<Region> region(launches.size(), Region{0, 0, false});
     static const size_t slab_budget = [] { const char* e = getenv("PC_SLAB_BUDGET"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)3 << 30; }();
     static const bool strips_in_line = getenv("PC_STRIP_STREAMS") && !strcmp(getenv("PC_STRIP_STREAMS"), "0");     // A/B: the r04 order
-    size_t shared = 0, sbytes = 0;
-    for (const Launch& l : launches) if (launch_variant(l) < 0) shared = std::max(shared, pc_nw_fallback_scratch_bytes(l.max_lb));
+    size_t sbytes = 0;
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t own_total = 0;
-    for (size_t i = 0; i < launches.size(); ++i) {
-        const Launch& l = launches[i];
-        const int v = launch_variant(l);
-        if (v < 0 || !pc_launch_is_strip(v, l.max_lb, l.mode, ppos)) continue;
-        const size_t need = up256(pc_nw_strip_launch_bytes(l.mode, (int)(l.end - l.begin), c->max_gene_len, c->n_cu, ppos));
-        if (!strips_in_line && c->n_streams > 1 && own_total + need <= slab_budget) { region[i] = Region{own_total, need, true}; own_total += need; }
-        else shared = std::max(shared, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
+    auto lay_out = [&](bool in_line) {                                    // regions of the slab; in_line: every strip-mined launch shares the first
+        size_t shared = 0, own_total = 0;
+        std::fill(region.begin(), region.end(), Region{0, 0, false});
+        for (const Launch& l : launches) if (launch_variant(l) < 0) shared = std::max(shared, pc_nw_fallback_scratch_bytes(l.max_lb));
+        for (size_t i = 0; i < launches.size(); ++i) {
+            const Launch& l = launches[i];
+            const int v = launch_variant(l);
+            if (v < 0 || !pc_launch_is_strip(v, l.max_lb, l.mode, ppos)) continue;
+            const size_t need = up256(pc_nw_strip_launch_bytes(l.mode, (int)(l.end - l.begin), c->max_gene_len, c->n_cu, ppos));
+            if (!in_line && c->n_streams > 1 && own_total + need <= slab_budget) { region[i] = Region{own_total, need, true}; own_total += need; }
+            else shared = std::max(shared, pc_nw_strip_scratch_bytes(c->max_gene_len, c->n_cu));
+        }
+        shared = up256(shared);
+        for (size_t i = 0; i < launches.size(); ++i) {
+            if (region[i].own) region[i].off += shared;
+            else if (uses_slab(launches[i])) region[i] = Region{0, shared, false};
+        }
+        sbytes = shared + own_total;
+        return own_total;
+    };
+    const size_t own_total = lay_out(strips_in_line);
+    if (sbytes) {
+        int rc = c->b_scratch.ensure(sbytes);
+        // The slab's own regions can reach 3 GB + 1 GB shared, and their size follows the chip and the longest gene, not the chunk: a
+        // chunked fill on a nearly full device would halve its chunk again and again without the slab getting any smaller.  So: once
+        // more with every strip-mined launch in line on the shared region (fewer bytes, same values) before the chunk is given up.
+        if (rc == PC_ERR_NOMEM_INTERNAL && own_total > 0) { lay_out(true); rc = sbytes ? c->b_scratch.ensure(sbytes) : PC_OK; }
+        if (rc != PC_OK) return rc;
     }
-    shared = up256(shared);
-    for (size_t i = 0; i < launches.size(); ++i) {
-        if (region[i].own) region[i].off += shared;
-        else if (uses_slab(launches[i])) region[i] = Region{0, shared, false};
-    }
-    sbytes = shared + own_total;
-    if (sbytes) { int rc = c->b_scratch.ensure(sbytes); if (rc != PC_OK) return rc; }
     // Launch classes of one register tier, cell and workgroup size share ONE launch (k_nw_systolic_tier, pc_nw_fuse_key): the
     // hardware queues run launches back to back, each waiting for the last workgroup of the one before it, and a fill's ~80
     // launches cost it a task's duration each -- bundled they are ~15, each holding more tasks than the chip does at once.
@@ -1370,8 +1387,9 @@ static int fill_aligned(pc_ctx* c, int metric, int ppos, int as_distance, double
             return PC_OK;
         }
         if (rc != PC_ERR_NOMEM_INTERNAL) return rc;
-        PC_HIP(hipStreamSynchronize(st));                                 // out of HBM: free the plan, go on in chunks of half the size
+        PC_HIP(hipStreamSynchronize(st));                                 // out of HBM: free the plan (and the strip-mined launches' slab), go on in chunks of half the size
         release_plan_buffers(c);
+        c->b_scratch.release();
         max_aln = std::max<uint64_t>(A / 2, 1);
         local.n_tasks = 0; local.n_distinct_alignments = local.n_distinct_cells = 0; local.n_align_launches = 0;
     }
@@ -1391,6 +1409,7 @@ static int fill_aligned(pc_ctx* c, int metric, int ppos, int as_distance, double
         if (rc == PC_ERR_NOMEM_INTERNAL && max_aln > 1 && k1 - k > 1) {                 // a retry with a smaller chunk, not an error
             PC_HIP(hipStreamSynchronize(st));
             release_plan_buffers(c);
+            c->b_scratch.release();
             max_aln = std::max<uint64_t>(std::min(max_aln, run) / 2, 1);
             continue;
         }
@@ -1464,12 +1483,24 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
         else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
-        // r05: gcs / jc: the column form of the counting mode (k_sparse_col: the masks over a block of targets stay in LDS for a run
-        // of source tiles, no barrier per tile) -- while its masks fit (<= 7,680 phams with two holders).  Against the popcount tiles
+        // r05: gcs / jc / pocp: the column form of the counting mode (k_sparse_col: the masks over a block of targets stay in LDS for a run
+        // of source tiles, no barrier per tile) -- while its masks (pocp: and its paralog list and bit sets) fit 78 KB of LDS.  Against the popcount tiles
         // (profiles/r05/experiments/sparse_col.txt; ms, popcount / column): 5,056 phams (79 words, 2.85 shared) N = 2,000 0.035 / 0.034,
         // 3,000 0.070 / 0.046, 8,000 0.35 / 0.20, 20,000 2.03 / 0.99; 2,500 phams (40 words) N = 5,000 0.098 / 0.110; 1,200: 0.067 / 0.146
-        const bool col_ok = counts && s64_ok && pc_sparse_col_lds(d.sp_W * 64) > 0;
-        if (col_ok && (double)d.Wb > 40.0 + 8.0 * shared && area >= (int64_t)PC_COL_MIN_N * PC_COL_MIN_N) kernel = K_SPARSE_COL;
+        const int sp_mode = counts ? (metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC) : PCW_POCP;
+        bool col_ok = metric != PC_AF && s64_ok && pc_sparse_col_lds(sp_mode, d.sp_W * 64) > 0;
+        if (col_ok && metric == PC_POCP) {                                 // ... and, pocp, every block of 64 targets' paralog entries fit its LDS list
+            const int cap = pc_sparse_col_para_cap();
+            for (size_t k0 = 0; k0 < c->h_owned.size() && col_ok; k0 += 64) {
+                uint32_t n = 0;
+                for (size_t k = k0; k < std::min(k0 + 64, c->h_owned.size()); ++k) { const int t = c->h_owned[k]; n += c->h_para_off[(size_t)t + 1] - c->h_para_off[(size_t)t]; }
+                col_ok = n <= (uint32_t)cap;
+            }
+        }
+        // (pocp, ms, popcount tiles / 64 x 64 sparse tiles / column: N = 2,000 0.066 / 0.082 / 0.057, 3,000 0.138 / 0.118 / 0.080, 5,000 0.306 / 0.214 / 0.164,
+        // 20,000 3.88 / 2.23 / 1.69)
+        const int64_t col_min_n = metric == PC_POCP ? 1800 : PC_COL_MIN_N;
+        if (col_ok && (double)d.Wb > 40.0 + 8.0 * shared && area >= col_min_n * col_min_n) kernel = K_SPARSE_COL;
         if (set_force) {
             if (!strcmp(set_force, "sparsecol") && col_ok) kernel = K_SPARSE_COL;
             if (!strcmp(set_force, "popc") && metric != PC_AF) kernel = K_POPC;
@@ -1479,8 +1510,8 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         }
     }
     if (metric < PC_AAI) c->last_set_kernel = kernel;
-    if ((metric == PC_GCS || metric == PC_JC) && kernel == K_SPARSE_COL) {
-        rc = pc_launch_sparse_col(metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC, d, c->shard, out, as_distance, condensed, st);
+    if (metric < PC_AF && kernel == K_SPARSE_COL) {
+        rc = pc_launch_sparse_col(metric == PC_GCS ? PCW_SPARSE_GCS : metric == PC_JC ? PCW_SPARSE_JC : PCW_POCP, d, c->shard, out, as_distance, condensed, st);
         if (rc != PC_OK) return rc;
         PC_HIP(hipEventRecord(c->ev[3], st));
         local.n_chunks = 1;

@@ -317,6 +317,15 @@ int pc_nw_task_mode(int lb, int rows, int variant) {
 }
 int pc_nw_small_modes_enabled() { return pc_nw_task_mode(64, 1, 0) != PC_MODE_CLASS; }
 
+// A wave of the systolic kernel keeps at most 64 rows (pc_nw_body: a lane-indexed row table) and takes ceil(R / (nw nseg)) nseg of a
+// task's R rows: nw waves hold any task of up to nw x min over nseg of floor(64 / nseg) nseg = nw x 52 rows (nseg = 13).  The planner
+// cuts tasks to the CLASS's waves per workgroup and to PC_TASK_ROWS (pc_nw_task_rows); the LAUNCH's waves are worked out on their own
+// (cell, percent-positives variant swap, small-task modes).  Should the two ever drift apart, rows beyond a wave's 64 would be dropped
+// without a fault -- their result slots left unwritten -- so every launch checks: tasks in their class's own shape need 52 nw >=
+// PC_TASK_ROWS, i.e. four waves; the one- / two-wave modes hold tasks of at most nseg / 2 nseg rows by construction (pc_nw_task_mode).
+static_assert(PC_TASK_ROWS <= 4 * 52, "four-wave workgroups must hold a full-size task");
+static bool pc_launch_holds_task_rows(int nw, int wave_mode) { return wave_mode != PC_MODE_CLASS || nw * 52 >= PC_TASK_ROWS; }
+
 // Shape of a systolic launch of one class: which cell it runs, waves per workgroup, dynamic LDS
 struct PcLaunchShape { int W, nw; bool inc16; size_t lds; };
 static int launch_shape(int variant, int max_lb, int ppos, int compare_only, int wave_mode, PcLaunchShape& sh) {
@@ -380,6 +389,7 @@ int pc_launch_nw_group(const PcNwSegment* segs, int nsegs, const PcDev& d, const
         PcLaunchShape sh;
         int rc = launch_shape(sg.variant, sg.max_lb, ppos, sg.compare_only, sg.wave_mode, sh);
         if (rc != PC_OK) return rc;
+        if (!pc_launch_holds_task_rows(sh.nw, sg.wave_mode)) { pc_set_error("pc_launch_nw_group: %d-wave workgroups cannot hold the rows of a full-size task (variant %d, %d columns)", sh.nw, sg.variant, sg.max_lb); return PC_ERR_STATE; }
         const int t = pc_tier_of(sh.W);
         if (i == 0) { tier = t; nw = sh.nw; inc16 = sh.inc16; }
         else if (t != tier || sh.nw != nw || sh.inc16 != inc16) { pc_set_error("pc_launch_nw_group: segments of different tier / cell / workgroup size"); return PC_ERR_ARG; }
@@ -402,6 +412,7 @@ static int launch_wide(const PcDev& d, const PcTask* tasks, int ntasks, const in
                        int max_lb, int wave_mode, int rule, hipStream_t st) {
     int Gmax = (max_lb + W - 1) / W; if (Gmax > 64) Gmax = 64; if (Gmax < 1) Gmax = 1;
     const int nw = wave_mode == PC_MODE_ONE_WAVE ? 1 : wave_mode == PC_MODE_TWO_WAVES ? 2 : waves_for(W, Gmax, 1);
+    if (!pc_launch_holds_task_rows(nw, wave_mode)) { pc_set_error("k_nw_systolic<%d>: %d-wave workgroups cannot hold the rows of a full-size task", W, nw); return PC_ERR_STATE; }
     const size_t lds = systolic_lds_bytes(W, Gmax, nw, false, false);
     hipError_t e = hipSuccess;
     switch (rule) {

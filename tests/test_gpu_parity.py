@@ -499,14 +499,14 @@ def test_strip_mined_long_column_genes(gpu_ctx, native_built):
             gpu_ctx.upload(pk)
             # PC_PIPE (read per launch): "0" one row per wave (the wide variants forced too); unset: the launcher's choice -- these few
             # tasks run pipelined, the passes of each alignment dealt over eight waves; 4, 3 (passes not a multiple of the waves), 1
-            want_fill = {metric: O.fill(pk, metric) for metric in ("aai", "peq")}
+            want_fill = {metric: O.fill(pk, metric) for metric in ("peq",)}      # (peq = round(af x aai): the same alignments and reduce as aai; one oracle pass over 20,000 x 20,000 cells less)
             for pipe in ("0", None, "4", "3", "1"):
                 if pipe is None: os.environ.pop("PC_PIPE", None)
                 else: os.environ["PC_PIPE"] = pipe
                 for variant in ((0, 32, 48, 64) if pipe == "0" else (0, 48)):
                     ident, diag = gpu_ctx.align_pairs(a, b, variant=variant)
                     assert np.array_equal(ident, wi) and np.array_equal(diag, wd), f"rule {rule} variant {variant} PC_PIPE {pipe}"
-                for metric in ("aai", "peq"):
+                for metric in want_fill:
                     assert np.array_equal(gpu_ctx.fill(metric), want_fill[metric]), f"rule {rule} {metric} PC_PIPE {pipe}"
             os.environ.pop("PC_PIPE", None)
             if rule == 0:
@@ -1401,7 +1401,7 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
             gpu_ctx.upload(packed, residues=False)
             for (m, dist), w in want.items():
                 assert np.array_equal(gpu_ctx.fill(m, dist), w), (kernel, m, dist)
-                assert gpu_ctx.last_set_kernel() == kernel or (kernel, m) == ("popc", "af") or kernel == "sparsecol", (kernel, m, gpu_ctx.last_set_kernel())   # (sparsecol: gcs / jc only)
+                assert gpu_ctx.last_set_kernel() == kernel or (kernel, m) in (("popc", "af"), ("sparsecol", "af")), (kernel, m, gpu_ctx.last_set_kernel())   # (af has no popcount and no column form)
             if kernel in ("popc", "sparse64", "sparsecol"):                  # gcs / jc: popcount tiles, or the sparse tiles' counting mode
                 for m in ("gcs", "jc"):
                     for dist in (True, False):
@@ -1808,3 +1808,54 @@ def test_reference_written_synth200(gpu_ctx, synth200_packed, metric):
     from phamclust_amd.matrix import SymMatrix
     m = SymMatrix.from_condensed(names, got, is_distance=True)
     assert m.get_weight(names[3], names[150]) == gold[3 * 200 - 3 * 4 // 2 + (150 - 3 - 1)]
+
+
+def test_column_kernel_pocp_paralog_list(gpu_ctx, native_built):
+    """pocp on the column kernel (k_sparse_col) adds the targets' paralog excess -- sum over shared phams of cnt_t - 1, metrics.py:102-110
+    -- from a list of a target block's paralog entries kept in LDS (1,024 of them).  A collection whose blocks hold a few hundred runs
+    there (unsharded and as a shard, every value against the oracle, counts up to 5 per pham); one whose blocks hold more must be
+    sent to another kernel by the selector, not truncated."""
+    import torch
+    from phamclust_amd.genome import Genome
+    from phamclust_amd.pack import pack_genomes
+    O = _oracle()
+    rng = np.random.default_rng(77)
+
+    def collection(n_genomes, paralogs_per_genome):
+        genomes = []
+        for k in range(n_genomes):
+            g = Genome(f"g{k:04d}")
+            phams = sorted(set(int(x) for x in rng.choice(900, size=int(rng.integers(30, 90)), replace=False)) | set(range(10 * (k % 7), 10 * (k % 7) + 25)))
+            para = set(int(x) for x in rng.choice(phams, size=min(paralogs_per_genome, len(phams)), replace=False))
+            for p in phams:
+                for _ in range(int(rng.integers(2, 6)) if p in para else 1):
+                    g.add(f"p{p:04d}", "MK" * int(rng.integers(1, 30)))
+            genomes.append(g)
+        return pack_genomes(genomes)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        os.environ["PC_SET_KERNEL"] = "sparsecol"
+        few = collection(200, 6)                                  # ~6 x 64 = 384 listed entries per block
+        gpu_ctx.upload(few, residues=False)
+        for dist in (True, False):
+            assert np.array_equal(gpu_ctx.fill("pocp", dist), O.fill(few, "pocp", dist)) and gpu_ctx.last_set_kernel() == "sparsecol"
+        gpu_ctx.set_shard(1, 3)
+        t_rank, t_lbase = gpu_ctx.shard_table()
+        want = O.fill(few, "pocp", True)
+        buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
+        gpu_ctx.fill_shard_dev("pocp", True, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert gpu_ctx.last_set_kernel() == "sparsecol"
+        got, n = buf.cpu().numpy(), few.n_genomes
+        for t in range(1, n):
+            if t_rank[t] == 1:
+                col = np.array([want[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
+                assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), t
+        gpu_ctx.set_shard(0, 1)
+        many = collection(130, 40)                                # 40 x 64 = 2,560 entries per block: beyond the list
+        gpu_ctx.upload(many, residues=False)
+        assert np.array_equal(gpu_ctx.fill("pocp"), O.fill(many, "pocp")) and gpu_ctx.last_set_kernel() != "sparsecol"
+        assert np.array_equal(gpu_ctx.fill("jc"), O.fill(many, "jc")) and gpu_ctx.last_set_kernel() == "sparsecol"
+    finally:
+        os.environ.pop("PC_SET_KERNEL", None)
