@@ -637,10 +637,20 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
     uint32_t* bnd = ring + PC_STRIP_WIN;                                 // [PC_STRIP_BND][4] staged boundary entries (Ho.hi, Ho.lo, E.hi, E.lo)
     constexpr int PROF_DW = (INC16 ? 2 * ((ROWS + 1) / 2) : ROWS) * RS * 64;     // one profile (PIPE: one per wave)
     uint32_t* prof = smem + 144 + NWV * pc_strip_wave_lds_dwords() + (PIPE ? wv * PROF_DW : 0);
-    // PIPE: word 0 of a wave's region = its progress (passes done << 17 | row steps done of the pass it is in)
-    typedef __attribute__((address_space(3))) volatile uint32_t pc_lds_vu32;
-    pc_lds_vu32* const prog_me = (pc_lds_vu32*)(size_t)(__attribute__((address_space(3))) uint32_t*)wreg;
-    pc_lds_vu32* const prog_prev = (pc_lds_vu32*)(size_t)(__attribute__((address_space(3))) uint32_t*)(smem + 144 + ((wv + NWV - 1) % NWV) * pc_strip_wave_lds_dwords());
+    // PIPE: word 0 of a wave's region = its progress (passes done << 17 | row steps done of the pass it is in).  Written with a
+    // workgroup-scope RELEASE store and read with an ACQUIRE load (r05): the order "boundary entries, then the word that announces
+    // them" is stated in the memory model, not only in the instruction stream.  What the model does not promise at that scope is that
+    // the entries have reached the L2 the reader's agent-scope loads are served from -- both waves sit on one CU, its L1 is write-through
+    // -- so the explicit `s_waitcnt vmcnt(0)` ahead of every publication stays (vmcnt counts stores on gfx9), and
+    // tools/check_pipe_publication.py holds the compiled kernels to it: in every k_nw_strip<..., PIPE> the last vector-memory wait
+    // before a progress store is vmcnt(0).  (An agent-scope release would write the L2 back, every 32 steps.)
+    typedef __attribute__((address_space(3))) uint32_t pc_lds_w32;           // (LDS-typed: ds_write / ds_read, not flat accesses)
+    pc_lds_w32* const prog_me = (pc_lds_w32*)(size_t)(pc_lds_w32*)wreg;
+    pc_lds_w32* const prog_prev = (pc_lds_w32*)(size_t)(pc_lds_w32*)(smem + 144 + ((wv + NWV - 1) % NWV) * pc_strip_wave_lds_dwords());
+    auto publish = [&](uint32_t value) {
+        asm volatile("s_waitcnt vmcnt(0) ; pc_publish: boundary entries before the progress word" ::: "memory");
+        if (lane == 0) __hip_atomic_store(prog_me, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     const uint32_t kcol = (uint32_t)(lane < Gl ? lane : lane - Gl) + (lane < Gl ? 0u : half_dw);
     uint4* const line = spill + ((size_t)blockIdx.x * (size_t)NWV + (size_t)wv) * spill_stride;
     // the line my left-hand boundary comes from: my own (the pass before was mine), PIPE: that of the wave with the pass before mine
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
         const int seg_len = have_row ? la + 1 : 0;                 // the virtual row -1, then the la residues
         if constexpr (PIPE) {
             __syncthreads();                                       // score table visible; every wave is done with the row before (its lines, its progress word)
-            if (lane == 0) *prog_me = 0u;
+            if (lane == 0) __hip_atomic_store(prog_me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __syncthreads();
         }
 #pragma unroll 1
@@ -739,16 +749,11 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
                     // (both waves sit on one CU: the stores must have reached the L2 they share -- vmcnt counts stores on gfx9, and the
                     // wait is spelled out because the compiler trimmed the fence's own down to lgkmcnt inside this loop -- and the reader's
                     // loads bypass the L1; an agent-scope fence would also write the whole L2 back, every 32 steps)
-                    if (!last_pass && base >= 2) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) *prog_me = (item << 17) + (uint32_t)(base - 2);
-                    }
+                    if (!last_pass && base >= 2) publish((item << 17) + (uint32_t)(base - 2));
                     // entries base .. base + 31 of the line I read were written at the other wave's steps base + 63 .. base + 94
                     if (pass > 0 && base < seg_len) {
                         const uint32_t need = ((uint32_t)((pass - 1) / NWV) << 17) + (uint32_t)base + 95u;     // (a finished pass counts as 1 << 17)
-                        while (*prog_prev < need) __builtin_amdgcn_s_sleep(4);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        while (__hip_atomic_load(prog_prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(4);
                     }
                 }
                 pc_wave_lds_sync();
@@ -889,11 +894,7 @@ __global__ __launch_bounds__(64 * (PIPE ? PC_PIPE_WAVES_MAX : PC_STRIP_WAVES), (
                 step(t + 1, false, a2, a);
             }
             }
-            if constexpr (PIPE) if (!last_pass) {                  // the whole line is written: whoever reads it need not look at steps any more
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) *prog_me = (item + 1u) << 17;
-            }
+            if constexpr (PIPE) if (!last_pass) publish((item + 1u) << 17);     // the whole line is written: whoever reads it need not look at steps any more
         }
         }
         __syncthreads();                                           // the next task rebuilds the profile

@@ -483,3 +483,16 @@ def test_gpus_request_is_clamped_to_the_work(native_built, tmp_path, monkeypatch
     line = startup.Timeline()
     line.mark("imports")
     assert line.line().startswith("timing: {") and "imports" in line.as_dict()
+
+
+def test_pipelined_strip_kernels_publish_after_their_stores():
+    """the pipelined form of k_nw_strip hands boundary lines from wave to wave through HBM; the progress word that
+    announces them must be stored after a vmcnt(0) wait (and, r05, with release / acquire atomics).  tools/check_pipe_publication.py
+    compiles the alignment units to gfx950 assembly and checks every such kernel; a compiler update that reorders or drops the wait
+    fails here, on the build machine, not as wrong scores on a GPU."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    run = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_pipe_publication.py")], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "8 pipelined strip kernels checked: ok" in run.stdout
