@@ -142,8 +142,7 @@ struct pc_ctx {
     int64_t n_residue_bytes_in = 0;         // residue bytes of the packed genomes part 1 saw (part 2 must be given the same)
     PcDev dev{};
     std::vector<int32_t> h_gene_len;
-    std::vector<uint32_t> h_para_off;                  // [N+1] host copy of the paralog-entry offsets (k_sparse_col's pocp mode: entries per block of targets)
-    std::vector<uint32_t> h_sp_n;                      // [N] a genome's entries of phams with at least two holders (k_sparse_col's af mode: values per block of targets)
+    std::vector<uint32_t> h_sp_n;                      // [N] a genome's entries of phams with at least two holders (k_sparse_col's pocp / af modes: values per block of targets)
     int max_ent_len = 0;                               // largest summed length of a (genome, pham) entry (k_sparse_col's af mode keeps them as 16-bit values)
     std::vector<uint8_t> h_gene_odd;                   // gene holds a byte outside the 24-letter alphabet
     int max_gene_len = 0, min_gene_len = 0, max_nph = 0, max_ngen = 0;
@@ -540,7 +539,6 @@ static int upload_sets(pc_ctx* c, const pc_packed* g) {
         }
         para_off[N] = (uint32_t)at;
         c->max_ngen = max_ngen;
-        c->h_para_off.assign(para_off, para_off + N + 1);
         c->h_sp_n.assign((size_t)N, 0u);
         int max_ent_len = 0;
         for (int s2 = 0; s2 < N; ++s2) {
@@ -1499,27 +1497,19 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         // 3,000 0.070 / 0.046, 8,000 0.35 / 0.20, 20,000 2.03 / 0.99; 2,500 phams (40 words) N = 5,000 0.098 / 0.110; 1,200: 0.067 / 0.146
         const int sp_mode = counts ? (metric == PC_GCS ? PCW_SPARSE_GCS : PCW_SPARSE_JC) : metric == PC_POCP ? PCW_POCP : PCW_AF;
         bool col_ok = s64_ok && pc_sparse_col_lds(sp_mode, d.sp_W * 64) > 0;
-        if (col_ok && metric == PC_POCP) {                                 // ... and, pocp, every block of 64 targets' paralog entries fit its LDS list
-            const int cap = pc_sparse_col_para_cap();
-            for (size_t k0 = 0; k0 < c->h_owned.size() && col_ok; k0 += 64) {
-                uint32_t n = 0;
-                for (size_t k = k0; k < std::min(k0 + 64, c->h_owned.size()); ++k) { const int t = c->h_owned[k]; n += c->h_para_off[(size_t)t + 1] - c->h_para_off[(size_t)t]; }
-                col_ok = n <= (uint32_t)cap;
-            }
-        }
-        if (col_ok && metric == PC_AF) {                                   // ... af: every block's entries fit its LDS value table, as 16-bit values
+        if (col_ok && !counts) {                                           // ... pocp / af: every block's entries fit its LDS value table, as 16-bit values
             const int cap = pc_sparse_col_vals_cap(d.sp_W * 64);
-            col_ok = c->max_ent_len < 65536;
+            col_ok = metric == PC_POCP || c->max_ent_len < 65536;         // (pocp: s64_ok already holds the gene counts below 65,536)
             for (size_t k0 = 0; k0 < c->h_owned.size() && col_ok; k0 += 64) {
                 uint32_t n = 0;
                 for (size_t k = k0; k < std::min(k0 + 64, c->h_owned.size()); ++k) n += c->h_sp_n[(size_t)c->h_owned[k]];
                 col_ok = n <= (uint32_t)cap;
             }
         }
-        // (pocp, ms, popcount tiles / 64 x 64 sparse tiles / column: N = 2,000 0.066 / 0.082 / 0.057, 3,000 0.138 / 0.118 / 0.080, 5,000 0.306 / 0.214 / 0.164,
-        // 20,000 3.88 / 2.23 / 1.69)
-        const int64_t col_min_n = metric == PC_POCP ? 1800 : PC_COL_MIN_N;
-        if (col_ok && metric != PC_AF && (double)d.Wb > 40.0 + 8.0 * shared && area >= col_min_n * col_min_n) kernel = K_SPARSE_COL;
+        // (ms, popcount tiles / 64 x 64 sparse tiles / column -- pocp: N = 2,000 0.066 / 0.082 / 0.078, 3,000 0.137 / 0.118 / 0.083, 5,000 0.304 / 0.217 / 0.156,
+        // 20,000 3.89 / 2.23 / 1.45; af: 2,000 - / 0.089 / 0.078, 3,000 - / 0.121 / 0.081, 5,000 - / 0.258 / 0.150, 20,000 - / 2.41 / 1.42)
+        const int64_t col_min_n = metric == PC_AF ? 1800 : PC_COL_MIN_N;
+        if (col_ok && (double)d.Wb > 40.0 + 8.0 * shared && area >= col_min_n * col_min_n) kernel = K_SPARSE_COL;
         if (set_force) {
             if (!strcmp(set_force, "sparsecol") && col_ok) kernel = K_SPARSE_COL;
             if (!strcmp(set_force, "popc") && metric != PC_AF) kernel = K_POPC;

@@ -119,8 +119,7 @@ int pc_launch_sp_build(int N, const uint32_t* ent_off, const int32_t* pham, cons
 int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st); // pocp / af, large matrices
 // k_sparse_col (gcs / jc / pocp, large matrices): masks over a block of target genomes kept in LDS across a run of source tiles
 size_t pc_sparse_col_lds(int mode, int P64);      // 0: the masks do not fit
-int pc_sparse_col_para_cap();                    // pocp: paralog entries (gene count > 1) a block of 64 targets may hold
-int pc_sparse_col_vals_cap(int P64);             // af: entries (of phams with two holders) a block of 64 targets may hold
+int pc_sparse_col_vals_cap(int P64);             // pocp / af: entries (of phams with two holders) a block of 64 targets may hold
 int pc_launch_sparse_col(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st);
 int pc_scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* tmp, int64_t tmp_elems, hipStream_t st);
 int64_t pc_scan_tmp_elems(int64_t n);

@@ -984,15 +984,16 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 //     waits for another wave: no barrier, and at 8 waves per SIMD another wave is always ready;
 //   * units are dealt so that XCD x takes the target blocks ty = x mod 8 and the runs of a block from the diagonal down (the
 //     diagonal tiles -- pairs inside a cluster share ~85 phams, ten times the work -- start first).
-// pocp runs here too: conserved(s, t) = sum over shared phams of cnt_s + cnt_t = sum (cnt_s + 1) + sum (cnt_t - 1).  The first sum is this
-// kernel with the value cnt_s + 1 per hit instead of 1.  The second has terms only where a TARGET holds the pham more than once (~6 % of
-// the entries): the block's paralog entries (pham, target, cnt - 1) are listed in LDS once per unit, and the wave that owns source row s
-// sets the row's phams in a bit set of its own (LDS, 4 bits per 32 phams) and walks that list, 64 entries per step, testing each
-// entry's pham in it -- again adding into its own row only.  (First version: the test read s's row of the genomes x phams bitmap
-// from HBM / L2 -- a gather per list step: N = 20,000 2.14 ms against 1.00 for jc.)
-// af stays on k_sparse_tile64: EVERY entry of a target has a value of its own to add, into rows of other waves, which needs the barriers
-// back; fetching that direction's masks -- the tile's sources -- from a transposed bitmap was built and measured (pocp 2.29 against 2.28
-// ms, af 2.62 against 2.46: a 64-line gather per load instruction).
+// pocp and af run here too (value modes): a hit adds the SOURCE entry's value (gene count, resp. summed length) and the TARGET's.  The
+// source's rides with the probing entry.  The target's is looked up: once per unit the block's values are laid out in LDS pham by pham
+// -- val_off[p] = where pham p's start (an exclusive prefix sum over the popcounts of the masks), then one 16-bit value per target that
+// holds p, in target order -- so the value of hit target o is vals[val_off[p] + popcount(mask below bit o)]: for the one or two hits an
+// entry adds itself the first (and second) value of the run, for a broadcast entry the lane of target l reads the value at the rank
+// v_mbcnt gives it.  Everything still lands in the probing wave's own rows: no barrier.  (Tried first and dropped, records in
+// profiles/r05/experiments/sparse_col.txt: the targets' direction through a transposed bitmap and shared accumulators -- af 2.62 ms;
+// pocp's paralog excess from an LDS list against the source row in the HBM bitmap -- 2.14 -- or against a per-wave bit set -- 1.69.)
+// Values are 16 bits: gene counts and summed lengths of an entry below 65,536, and a block's entries within what two workgroups per
+// CU leave beside masks, offsets and accumulators (~7,000 at 5,056 phams) -- the host checks both and sends the rest to k_sparse_tile64.
 // Needs 8 B x phams-with-two-holders of LDS beside the accumulators: up to 7,680 such phams; beyond, or for small matrices, the
 // kernels above run.  No MFMA: this is a sparse join, ~3 shared phams per pair.
 // ---------------------------------------------------------------------------------
@@ -1000,18 +1001,18 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 #define S7_B 2                                                    // 64-entry batches of a row held in registers (a row's ~100 entries)
 #define S7_WAVES 16
 #define S7_RPW (S6_T / S7_WAVES)                                  // rows (of either side) a wave owns
-#define S7_PARA_CAP 1024                                          // pocp: paralog entries of a target block listed in LDS (the host checks the shard's blocks against it)
 template <int MODE>
 __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int P64, int nty, int seg) {
-    static_assert(MODE == S6_GCS || MODE == S6_JC || MODE == PCW_POCP, "gcs, jc, pocp");
-    constexpr bool POCP = MODE == PCW_POCP;
+    static_assert(MODE == S6_GCS || MODE == S6_JC || MODE == PCW_POCP || MODE == PCW_AF, "gcs, jc, pocp, af");
+    constexpr bool POCP = MODE == PCW_POCP, AF = MODE == PCW_AF;
+    constexpr bool VAL = POCP || AF;                                                // a hit adds a value of the source's entry, not 1
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
     uint32_t* colmask = sp_lds;                                                    // [P64][2]: which of the block's 64 targets hold the pham
     uint32_t* acc = sp_lds + 2 * P64;                                              // [64 sources][65]
-    uint2* para = (uint2*)(acc + S6_T * S6_LD);                                    // pocp: [S7_PARA_CAP] (pham, target row << 16 | cnt - 1)   (8-byte aligned: 2 P64 + 4,160 dwords)
-    __shared__ int para_n;
-    const int BW = P64 / 32;                                                       // pocp: words of a wave's bit set over the phams
-    uint32_t* bits = (uint32_t*)(para + S7_PARA_CAP) + (size_t)(threadIdx.x >> 6) * BW;
+    // pocp / af: the TARGETS' values, looked up per hit: vals[val_off[p] + (rank of the hit's target among the targets that hold p)]
+    uint16_t* val_off = (uint16_t*)(acc + S6_T * S6_LD);                           // [P64] start of pham p's values
+    uint16_t* vals = val_off + P64;                                                // [<= pc_sparse_col_vals_cap] gene counts / summed lengths, 16 bits each (the host checked)
+    __shared__ uint32_t scan_w[S7_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // unit of this workgroup
     const unsigned xcd = blockIdx.x & 7u, kk = blockIdx.x >> 3;
@@ -1027,14 +1028,13 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
 
     // ---- once per unit: the masks over the targets
     const int gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;           // lane l <-> target row l, for the whole unit
-    const uint32_t tot_t_l = gt_l >= 0 ? (uint32_t)(POCP ? d.ngen[gt_l] : d.nph[gt_l]) : 0u;
+    const uint32_t tot_t_l = gt_l >= 0 ? (uint32_t)(POCP ? d.ngen[gt_l] : AF ? (int)d.tlen[gt_l] : d.nph[gt_l]) : 0u;
     const int64_t lbase_l = (!condensed && gt_l >= 0) ? sh.lbase[k0 + lane] : 0;
     {
         uint32_t rl_t = 0, rh_t = 0;
         if (gt_l >= 0) { rl_t = d.ent_off[gt_l]; rh_t = d.sp_end[gt_l]; }
         uint32_t lo_t[S7_RPW], hi_t[S7_RPW];
-        int ph_t[S7_RPW][S7_B]; uint32_t ex_t[POCP ? S7_RPW : 1][POCP ? S7_B : 1];      // pocp: gene count - 1
-        if (POCP && tid == 0) para_n = 0;
+        int ph_t[S7_RPW][S7_B]; uint32_t ex_t[VAL ? S7_RPW : 1][VAL ? S7_B : 1];        // pocp: gene count; af: summed length
 #pragma unroll
         for (int rr = 0; rr < S7_RPW; ++rr) {
             const int r = wave + S7_WAVES * rr;
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
 #pragma unroll
             for (int b = 0; b < S7_B; ++b) {
                 const uint32_t et = lo_t[rr] + (uint32_t)(64 * b + lane);
-                if constexpr (POCP) { const uint2 x = et < hi_t[rr] ? d.sp_cnt[et] : make_uint2(0xffffffffu, 0u); ph_t[rr][b] = (int)x.x; ex_t[rr][b] = x.y - 1u; }
+                if constexpr (VAL) { const uint2 x = et < hi_t[rr] ? (AF ? d.sp_len : d.sp_cnt)[et] : make_uint2(0xffffffffu, 0u); ph_t[rr][b] = (int)x.x; ex_t[rr][b] = x.y; }
                 else ph_t[rr][b] = et < hi_t[rr] ? d.sp_pham[et] : -1;
             }
         for (int i = tid * 4; i < 2 * P64; i += 256 * S7_WAVES) *(uint4*)&colmask[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1056,21 +1056,41 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
             const int r = wave + S7_WAVES * rr;
             const uint32_t bit = 1u << (r & 31); const int half = r >> 5;
 #pragma unroll
-            for (int b = 0; b < S7_B; ++b) if (ph_t[rr][b] >= 0) {
-                atomicOr(&colmask[2 * ph_t[rr][b] + half], bit);
-                if constexpr (POCP) if (ex_t[rr][b] > 0u) {                            // a paralog entry of the block: listed (the host made sure they fit)
-                    const int at = atomicAdd(&para_n, 1);
-                    if (at < S7_PARA_CAP) para[at] = make_uint2((uint32_t)ph_t[rr][b], ((uint32_t)r << 16) | ex_t[rr][b]);
-                }
-            }
+            for (int b = 0; b < S7_B; ++b) if (ph_t[rr][b] >= 0) atomicOr(&colmask[2 * ph_t[rr][b] + half], bit);
             for (uint32_t e0 = lo_t[rr] + 64u * S7_B; e0 < hi_t[rr]; e0 += 64u) {            // rows with more entries than the registers hold
                 const uint32_t e = e0 + (uint32_t)lane;
-                if (e < hi_t[rr]) {
-                    if constexpr (POCP) {
-                        const uint2 x = d.sp_cnt[e];
-                        atomicOr(&colmask[2 * x.x + half], bit);
-                        if (x.y > 1u) { const int at = atomicAdd(&para_n, 1); if (at < S7_PARA_CAP) para[at] = make_uint2(x.x, ((uint32_t)r << 16) | (x.y - 1u)); }
-                    } else atomicOr(&colmask[2 * d.sp_pham[e] + half], bit);
+                if (e < hi_t[rr]) atomicOr(&colmask[2 * d.sp_pham[e] + half], bit);
+            }
+        }
+        if constexpr (VAL) {
+            // val_off = exclusive prefix sum over the phams of the number of targets that hold them (a thread takes a run of phams,
+            // the waves' totals meet in LDS), then every target entry drops its value at its pham's start + its row's rank in the mask
+            __syncthreads();                                                        // masks complete
+            const int per = (P64 + 64 * S7_WAVES - 1) / (64 * S7_WAVES), p_lo = tid * per, p_hi = min(P64, p_lo + per);
+            uint32_t mine = 0;
+            for (int p = p_lo; p < p_hi; ++p) mine += (uint32_t)(__popc(colmask[2 * p]) + __popc(colmask[2 * p + 1]));
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += up; }
+            if (lane == 63) scan_w[wave] = incl;
+            __syncthreads();
+            uint32_t base = incl - mine;
+            for (int w = 0; w < wave; ++w) base += scan_w[w];
+            for (int p = p_lo; p < p_hi; ++p) { val_off[p] = (uint16_t)base; base += (uint32_t)(__popc(colmask[2 * p]) + __popc(colmask[2 * p + 1])); }
+            __syncthreads();
+            auto drop = [&](int r, int p, uint32_t v) {
+                const uint2 m = *(const uint2*)&colmask[2 * p];
+                const int rank = r < 32 ? __popc(m.x & ((1u << r) - 1u)) : __popc(m.x) + __popc(m.y & ((1u << (r - 32)) - 1u));
+                vals[(int)val_off[p] + rank] = (uint16_t)v;
+            };
+#pragma unroll
+            for (int rr = 0; rr < S7_RPW; ++rr) {
+                const int r = wave + S7_WAVES * rr;
+#pragma unroll
+                for (int b = 0; b < S7_B; ++b) if (ph_t[rr][b] >= 0) drop(r, ph_t[rr][b], ex_t[rr][b]);
+                for (uint32_t e0 = lo_t[rr] + 64u * S7_B; e0 < hi_t[rr]; e0 += 64u) {
+                    const uint32_t e = e0 + (uint32_t)lane;
+                    if (e < hi_t[rr]) { const uint2 x = (AF ? d.sp_len : d.sp_cnt)[e]; drop(r, (int)x.x, x.y); }
                 }
             }
         }
@@ -1078,34 +1098,41 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
     // the sources' entry ranges, one tile ahead
     uint32_t rl_s = 0, rh_s = 0;
     { const int g = tx0 * S6_T + lane; if (g < d.N) { rl_s = d.ent_off[g]; rh_s = d.sp_end[g]; } }
-    __syncthreads();                                                                // masks complete: from here on no wave waits for another
-    const int n_para = POCP ? min(para_n, S7_PARA_CAP) : 0;
+    __syncthreads();                                                                // masks (and values) complete: from here on no wave waits for another
 
     // one probe step of source row r: 64 entries (one per lane), each with the 64-bit mask m of the targets that hold its pham.  Up
     // to two hits the lane adds itself (LDS); more are BROADCAST: the mask becomes the EXEC mask of one v_add into hs, which lane l
     // holds for target l (k_sparse_tile64's step; raising the threshold with a loop per lane -- 3, 4, 6 hits -- changed nothing)
-    auto step = [&](int r, uint2 m, uint32_t v, uint32_t& hs) {                     // v: what a hit adds (1; pocp: the source's gene count + 1)
+    auto step = [&](int r, uint2 m, uint32_t v, uint32_t off, uint32_t& hs) {      // v: what a hit adds (1; pocp / af: the source's gene count / length, + the target's from vals[off + rank])
         const int pc = __popc(m.x) + __popc(m.y);
         if (pc > 0 && pc <= 2) {
             const unsigned long long mm = ((unsigned long long)m.y << 32) | m.x;
             const int o1 = __builtin_ctzll(mm), o2 = 63 - __builtin_clzll(mm);
-            atomicAdd(&acc[r * S6_LD + o1], v);
-            if (pc == 2) atomicAdd(&acc[r * S6_LD + o2], v);
+            if constexpr (VAL) {
+                const uint32_t t1 = vals[off], t2 = vals[off + 1];                  // (one entry of padding behind the table)
+                atomicAdd(&acc[r * S6_LD + o1], v + t1);
+                if (pc == 2) atomicAdd(&acc[r * S6_LD + o2], v + t2);
+            } else {
+                atomicAdd(&acc[r * S6_LD + o1], v);
+                if (pc == 2) atomicAdd(&acc[r * S6_LD + o2], v);
+            }
         }
         unsigned long long heavy = __ballot(pc > 2);
         while (heavy) {
             const int k = __builtin_ctzll(heavy);
             asm("s_bitset0_b64 %0, %1" : "+s"(heavy) : "s"(k));
-            const unsigned long long mk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m.y, k) << 32) |
-                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m.x, k);
+            const uint32_t mkl = (uint32_t)__builtin_amdgcn_readlane((int)m.x, k), mkh = (uint32_t)__builtin_amdgcn_readlane((int)m.y, k);
+            const unsigned long long mk = ((unsigned long long)mkh << 32) | (unsigned long long)mkl;
             // (every lane of the workgroup is active here -- wave-uniform control flow -- so EXEC is all ones before and after)
-            if constexpr (POCP) {
-                const uint32_t vk = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
-                asm volatile("s_mov_b64 exec, %1\n\tv_add_u32 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(hs) : "s"(mk), "s"(vk));
+            if constexpr (VAL) {
+                // lane l <-> target l: where bit l of the entry's mask is set, its own value + target l's, found at the rank of bit l
+                const uint32_t vk = (uint32_t)__builtin_amdgcn_readlane((int)v, k), offk = (uint32_t)__builtin_amdgcn_readlane((int)off, k);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mkh, __builtin_amdgcn_mbcnt_lo(mkl, 0u));
+                if ((mk >> lane) & 1ULL) hs += vk + (uint32_t)vals[offk + rank];
             } else asm volatile("s_mov_b64 exec, %1\n\tv_add_u32 %0, %0, 1\n\ts_mov_b64 exec, -1" : "+v"(hs) : "s"(mk));
         }
     };
-    const uint2* __restrict__ ent = d.sp_cnt;                                       // pocp: (dense pham id, gene count) in one 8-byte load
+    const uint2* __restrict__ ent = AF ? d.sp_len : d.sp_cnt;                       // pocp / af: (dense pham id, gene count / summed length) in one 8-byte load
 
 #pragma unroll 1
     for (int tx = tx0; tx < tx1; ++tx) {
@@ -1116,13 +1143,13 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
             const int r = wave + S7_WAVES * rr;
             lo_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rl_s, r); hi_s[rr] = (uint32_t)__builtin_amdgcn_readlane((int)rh_s, r);
         }
-        int ph_s[S7_RPW][S7_B]; uint32_t v_s[POCP ? S7_RPW : 1][POCP ? S7_B : 1];
+        int ph_s[S7_RPW][S7_B]; uint32_t v_s[VAL ? S7_RPW : 1][VAL ? S7_B : 1];
 #pragma unroll
         for (int rr = 0; rr < S7_RPW; ++rr)
 #pragma unroll
             for (int b = 0; b < S7_B; ++b) {
                 const uint32_t es = lo_s[rr] + (uint32_t)(64 * b + lane);
-                if constexpr (POCP) { const uint2 x = es < hi_s[rr] ? ent[es] : make_uint2(0xffffffffu, 0u); ph_s[rr][b] = (int)x.x; v_s[rr][b] = x.y + 1u; }
+                if constexpr (VAL) { const uint2 x = es < hi_s[rr] ? ent[es] : make_uint2(0xffffffffu, 0u); ph_s[rr][b] = (int)x.x; v_s[rr][b] = x.y; }
                 else ph_s[rr][b] = es < hi_s[rr] ? d.sp_pham[es] : -1;
             }
         rl_s = 0; rh_s = 0;                                                         // the next tile's ranges: in flight while this one is probed
@@ -1134,38 +1161,28 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
         for (int rr = 0; rr < S7_RPW; ++rr)
 #pragma unroll
             for (int b = 0; b < S7_B; ++b) ms[rr][b] = ph_s[rr][b] >= 0 ? *(const uint2*)&colmask[2 * ph_s[rr][b]] : make_uint2(0u, 0u);
+        uint32_t offs[VAL ? S7_RPW : 1][VAL ? S7_B : 1];
+        if constexpr (VAL) {
+#pragma unroll
+            for (int rr = 0; rr < S7_RPW; ++rr)
+#pragma unroll
+                for (int b = 0; b < S7_B; ++b) offs[rr][b] = ph_s[rr][b] >= 0 ? (uint32_t)val_off[ph_s[rr][b]] : 0u;
+        }
         uint32_t hs[S7_RPW];
 #pragma unroll
         for (int rr = 0; rr < S7_RPW; ++rr) {
             const int r = wave + S7_WAVES * rr;
             hs[rr] = 0u;
 #pragma unroll
-            for (int b = 0; b < S7_B; ++b) step(r, ms[rr][b], POCP ? v_s[rr][b] : 1u, hs[rr]);
+            for (int b = 0; b < S7_B; ++b) step(r, ms[rr][b], VAL ? v_s[rr][b] : 1u, VAL ? offs[rr][b] : 0u, hs[rr]);
             for (uint32_t e0 = lo_s[rr] + 64u * S7_B; e0 < hi_s[rr]; e0 += 64u) {
                 const uint32_t e = e0 + (uint32_t)lane;
-                uint2 m = make_uint2(0u, 0u); uint32_t v = 1u;
+                uint2 m = make_uint2(0u, 0u); uint32_t v = 1u, off = 0u;
                 if (e < hi_s[rr]) {
-                    if constexpr (POCP) { const uint2 x = ent[e]; m = *(const uint2*)&colmask[2 * x.x]; v = x.y + 1u; }
+                    if constexpr (VAL) { const uint2 x = ent[e]; m = *(const uint2*)&colmask[2 * x.x]; v = x.y; off = (uint32_t)val_off[x.x]; }
                     else m = *(const uint2*)&colmask[2 * d.sp_pham[e]];
                 }
-                step(r, m, v, hs[rr]);
-            }
-            if constexpr (POCP) {
-                // the targets' paralog excess: listed entry (pham p, target row o, cnt_t - 1) adds where source row r holds p.  The row's
-                // phams as a bit set in this wave's own LDS words, then the list against it, 64 entries per step.
-                if (n_para > 0) {
-                    for (int i = lane; i < BW; i += 64) bits[i] = 0u;
-#pragma unroll
-                    for (int b = 0; b < S7_B; ++b) if (ph_s[rr][b] >= 0) atomicOr(&bits[ph_s[rr][b] >> 5], 1u << (ph_s[rr][b] & 31));
-                    for (uint32_t e0 = lo_s[rr] + 64u * S7_B; e0 < hi_s[rr]; e0 += 64u) {
-                        const uint32_t e = e0 + (uint32_t)lane;
-                        if (e < hi_s[rr]) { const int p = d.sp_pham[e]; atomicOr(&bits[p >> 5], 1u << (p & 31)); }
-                    }
-                    for (int j = lane; j < n_para; j += 64) {
-                        const uint2 x = para[j];
-                        if ((bits[x.x >> 5] >> (x.x & 31u)) & 1u) atomicAdd(&acc[r * S6_LD + (int)(x.y >> 16)], x.y & 0xffffu);
-                    }
-                }
+                step(r, m, v, off, hs[rr]);
             }
         }
         // finish the wave's own rows: lane l <-> target l.  (The wave's LDS adds above and the reads below are one in-order queue.)
@@ -1180,24 +1197,32 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
             if (s >= d.N) continue;
             const int t = gt_l;
             if (t < 0 || s >= t) continue;
-            const uint32_t tot = (uint32_t)(POCP ? d.ngen[s] : d.nph[s]) + tot_t_l;
+            const uint32_t tot = (uint32_t)(POCP ? d.ngen[s] : AF ? (int)d.tlen[s] : d.nph[s]) + tot_t_l;
             const int64_t idx = condensed ? (int64_t)s * d.N - (int64_t)s * (s + 1) / 2 + (t - s - 1) : lbase_l + s;
-            out[idx] = pc_set_value<POCP ? PC_POCP : MODE == S6_GCS ? PC_GCS : PC_JC>((int)(cons_q[rr] + hs[rr]), (int)tot, as_distance);   // metrics.py:45-53 (gcs), 75-80 (jc), 104-110 (pocp)
+            if constexpr (AF) {                                                     // metrics.py:149-152: totals up to 2^32 - 2, so unsigned
+                const uint32_t cons = cons_q[rr] + hs[rr];
+                out[idx] = pc_finish(cons ? (double)cons / (double)tot : 0.0, as_distance);
+            } else out[idx] = pc_set_value<POCP ? PC_POCP : MODE == S6_GCS ? PC_GCS : PC_JC>((int)(cons_q[rr] + hs[rr]), (int)tot, as_distance);   // metrics.py:45-53 (gcs), 75-80 (jc), 104-110 (pocp)
         }
     }
 }
 
 // LDS the column kernel takes for a collection with P64 mask entries; 0: it cannot run (masks beyond 7,680 phams)
+// pocp / af: what two workgroups per CU leave for the targets' values, 16 bits each (+ one entry of padding); < 1,024: the mode is off
+int pc_sparse_col_vals_cap(int P64) {
+    const long long room = 80 * 1024 - 256 - ((long long)P64 * 8 + (long long)S6_T * S6_LD * 4 + (long long)P64 * 2);
+    return room / 2 - 1 >= 1024 ? (int)(room / 2 - 1) : 0;
+}
 size_t pc_sparse_col_lds(int mode, int P64) {
-    const size_t bytes = (size_t)P64 * 8 + (size_t)S6_T * S6_LD * 4 + (mode == PCW_POCP ? (size_t)S7_PARA_CAP * 8 + (size_t)S7_WAVES * (P64 / 32) * 4 : 0);
+    if (mode == PCW_AF || mode == PCW_POCP) return pc_sparse_col_vals_cap(P64) ? (size_t)80 * 1024 - 256 : 0;
+    const size_t bytes = (size_t)P64 * 8 + (size_t)S6_T * S6_LD * 4;
     return bytes <= 78 * 1024 ? bytes : 0;                                          // two workgroups per CU
 }
-int pc_sparse_col_para_cap() { return S7_PARA_CAP; }
 int pc_launch_sparse_col(int mode, const PcDev& d, const PcShard& sh, double* out, int as_distance, int condensed, hipStream_t st) {
     if (sh.nown <= 0 || d.N <= 1) return PC_OK;
     const int P64 = d.sp_W * 64;
     const size_t lds = pc_sparse_col_lds(mode, P64);
-    if (!lds || (mode != S6_GCS && mode != S6_JC && mode != PCW_POCP)) { pc_set_error("k_sparse_col: mode %d, %d mask entries", mode, P64); return PC_ERR_LIMIT; }
+    if (!lds || (mode != S6_GCS && mode != S6_JC && mode != PCW_POCP && mode != PCW_AF)) { pc_set_error("k_sparse_col: mode %d, %d mask entries", mode, P64); return PC_ERR_LIMIT; }
     const int nty = (sh.nown + S6_T - 1) / S6_T, ntx = (d.N + S6_T - 1) / S6_T;
     // source tiles per unit: as many as leave ~2 units per workgroup slot of the chip (2 slots per CU), at most S7_SEG.  Measured, jc, ms
     // (profiles/r05/experiments/sparse_col.txt): N = 2,000 / 3,000 / 5,000 / 20,000 with 1 tile per unit 0.034 / 0.046 / 0.105 / 1.27,
@@ -1209,6 +1234,7 @@ int pc_launch_sparse_col(int mode, const PcDev& d, const PcShard& sh, double* ou
     dim3 grid(((unsigned)nty + 7u) / 8u * 8u * runs), block(64 * S7_WAVES);
     if (mode == S6_GCS) hipLaunchKernelGGL((k_sparse_col<S6_GCS>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
     else if (mode == PCW_POCP) hipLaunchKernelGGL((k_sparse_col<PCW_POCP>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
+    else if (mode == PCW_AF) hipLaunchKernelGGL((k_sparse_col<PCW_AF>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
     else hipLaunchKernelGGL((k_sparse_col<S6_JC>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_col launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }

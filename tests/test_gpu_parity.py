@@ -1401,7 +1401,7 @@ def test_every_pocp_af_kernel_agrees(gpu_ctx, native_built):
             gpu_ctx.upload(packed, residues=False)
             for (m, dist), w in want.items():
                 assert np.array_equal(gpu_ctx.fill(m, dist), w), (kernel, m, dist)
-                assert gpu_ctx.last_set_kernel() == kernel or (kernel, m) in (("popc", "af"), ("sparsecol", "af")), (kernel, m, gpu_ctx.last_set_kernel())   # (af has no popcount and no column form)
+                assert gpu_ctx.last_set_kernel() == kernel or (kernel, m) == ("popc", "af"), (kernel, m, gpu_ctx.last_set_kernel())   # (af has no popcount form)
             if kernel in ("popc", "sparse64", "sparsecol"):                  # gcs / jc: popcount tiles, or the sparse tiles' counting mode
                 for m in ("gcs", "jc"):
                     for dist in (True, False):
@@ -1810,52 +1810,63 @@ def test_reference_written_synth200(gpu_ctx, synth200_packed, metric):
     assert m.get_weight(names[3], names[150]) == gold[3 * 200 - 3 * 4 // 2 + (150 - 3 - 1)]
 
 
-def test_column_kernel_pocp_paralog_list(gpu_ctx, native_built):
-    """pocp on the column kernel (k_sparse_col) adds the targets' paralog excess -- sum over shared phams of cnt_t - 1, metrics.py:102-110
-    -- from a list of a target block's paralog entries kept in LDS (1,024 of them).  A collection whose blocks hold a few hundred runs
-    there (unsharded and as a shard, every value against the oracle, counts up to 5 per pham); one whose blocks hold more must be
-    sent to another kernel by the selector, not truncated."""
+def test_column_kernel_value_modes(gpu_ctx, native_built):
+    """pocp and af on the column kernel (k_sparse_col): a hit adds the source entry's value and the TARGET's, which is looked up in a
+    table of the target block's values laid out pham by pham in LDS (16-bit values, as many as two workgroups per CU leave room for).
+    Collections with few and with many paralogs (counts up to 5 per pham) run there -- unsharded and as a shard, every value against
+    the oracle (metrics.py:83-157); one whose blocks hold more entries than the table, and one with an entry whose summed length
+    passes 65,535 (af), must be sent to another kernel by the selector, not truncated -- while gcs / jc keep the column kernel."""
     import torch
     from phamclust_amd.genome import Genome
     from phamclust_amd.pack import pack_genomes
     O = _oracle()
     rng = np.random.default_rng(77)
 
-    def collection(n_genomes, paralogs_per_genome):
+    def collection(n_genomes, paralogs_per_genome, n_phams=900, per_genome=(30, 90), long_entry=False):
         genomes = []
         for k in range(n_genomes):
             g = Genome(f"g{k:04d}")
-            phams = sorted(set(int(x) for x in rng.choice(900, size=int(rng.integers(30, 90)), replace=False)) | set(range(10 * (k % 7), 10 * (k % 7) + 25)))
+            phams = sorted(set(int(x) for x in rng.choice(n_phams, size=int(rng.integers(*per_genome)), replace=False)) | set(range(10 * (k % 7), 10 * (k % 7) + 25)))
             para = set(int(x) for x in rng.choice(phams, size=min(paralogs_per_genome, len(phams)), replace=False))
             for p in phams:
                 for _ in range(int(rng.integers(2, 6)) if p in para else 1):
                     g.add(f"p{p:04d}", "MK" * int(rng.integers(1, 30)))
+            if long_entry and k == 3:
+                g.add("p0001", "A" * 40000); g.add("p0001", "C" * 40000)          # one (genome, pham) entry of > 80,000 residues
             genomes.append(g)
         return pack_genomes(genomes)
 
     stream = torch.cuda.current_stream().cuda_stream
     try:
         os.environ["PC_SET_KERNEL"] = "sparsecol"
-        few = collection(200, 6)                                  # ~6 x 64 = 384 listed entries per block
-        gpu_ctx.upload(few, residues=False)
-        for dist in (True, False):
-            assert np.array_equal(gpu_ctx.fill("pocp", dist), O.fill(few, "pocp", dist)) and gpu_ctx.last_set_kernel() == "sparsecol"
-        gpu_ctx.set_shard(1, 3)
-        t_rank, t_lbase = gpu_ctx.shard_table()
-        want = O.fill(few, "pocp", True)
-        buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
-        gpu_ctx.fill_shard_dev("pocp", True, buf.data_ptr(), stream)
-        torch.cuda.synchronize()
-        assert gpu_ctx.last_set_kernel() == "sparsecol"
-        got, n = buf.cpu().numpy(), few.n_genomes
-        for t in range(1, n):
-            if t_rank[t] == 1:
-                col = np.array([want[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
-                assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), t
-        gpu_ctx.set_shard(0, 1)
-        many = collection(130, 40)                                # 40 x 64 = 2,560 entries per block: beyond the list
-        gpu_ctx.upload(many, residues=False)
-        assert np.array_equal(gpu_ctx.fill("pocp"), O.fill(many, "pocp")) and gpu_ctx.last_set_kernel() != "sparsecol"
-        assert np.array_equal(gpu_ctx.fill("jc"), O.fill(many, "jc")) and gpu_ctx.last_set_kernel() == "sparsecol"
+        for packed in (collection(200, 6), collection(130, 40)):
+            gpu_ctx.upload(packed, residues=False)
+            for m in ("pocp", "af"):
+                for dist in (True, False):
+                    assert np.array_equal(gpu_ctx.fill(m, dist), O.fill(packed, m, dist)) and gpu_ctx.last_set_kernel() == "sparsecol", (m, dist)
+            gpu_ctx.set_shard(1, 3)
+            t_rank, t_lbase = gpu_ctx.shard_table()
+            n = packed.n_genomes
+            for m in ("pocp", "af"):
+                want = O.fill(packed, m, True)
+                buf = torch.full((gpu_ctx.shard_stride(),), -1.0, dtype=torch.float64, device="cuda:0")
+                gpu_ctx.fill_shard_dev(m, True, buf.data_ptr(), stream)
+                torch.cuda.synchronize()
+                assert gpu_ctx.last_set_kernel() == "sparsecol"
+                got = buf.cpu().numpy()
+                for t in range(1, n):
+                    if t_rank[t] == 1:
+                        col = np.array([want[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
+                        assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), (m, t)
+            gpu_ctx.set_shard(0, 1)
+        crowded = collection(100, 5, n_phams=5000, per_genome=(380, 420))          # 64 x ~400 entries per block: more than the value table holds
+        gpu_ctx.upload(crowded, residues=False)
+        for m in ("pocp", "af"):
+            assert np.array_equal(gpu_ctx.fill(m), O.fill(crowded, m)) and gpu_ctx.last_set_kernel() != "sparsecol", m
+        assert np.array_equal(gpu_ctx.fill("jc"), O.fill(crowded, "jc")) and gpu_ctx.last_set_kernel() == "sparsecol"
+        longish = collection(90, 6, long_entry=True)
+        gpu_ctx.upload(longish, residues=False)
+        assert np.array_equal(gpu_ctx.fill("af"), O.fill(longish, "af")) and gpu_ctx.last_set_kernel() != "sparsecol"
+        assert np.array_equal(gpu_ctx.fill("pocp"), O.fill(longish, "pocp")) and gpu_ctx.last_set_kernel() == "sparsecol"
     finally:
         os.environ.pop("PC_SET_KERNEL", None)
