@@ -982,8 +982,8 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 //     alone -- its direct adds go to LDS (atomics: two entries of a row may hit the same target), its broadcast adds stay in a
 //     register per row -- and the same wave finishes the row's 64 pairs (fp64 epilogue, one coalesced store).  Nothing in a tile
 //     waits for another wave: no barrier, and at 8 waves per SIMD another wave is always ready;
-//   * units are dealt so that XCD x takes the target blocks ty = x mod 8 and the runs of a block from the diagonal down (the
-//     diagonal tiles -- pairs inside a cluster share ~85 phams, ten times the work -- start first).
+//   * units are dealt so that XCD x takes the target blocks ty = x mod 8, run after run of source tiles (see `tx0` in the kernel): the
+//     workgroups an XCD holds at a time read the same source rows.
 // pocp and af run here too (value modes): a hit adds the SOURCE entry's value (gene count, resp. summed length) and the TARGET's.  The
 // source's rides with the probing entry.  The target's is looked up: once per unit the block's values are laid out in LDS pham by pham
 // -- val_off[p] = where pham p's start (an exclusive prefix sum over the popcounts of the masks), then one 16-bit value per target that
@@ -1002,7 +1002,7 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 #define S7_WAVES 16
 #define S7_RPW (S6_T / S7_WAVES)                                  // rows (of either side) a wave owns
 template <int MODE>
-__global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int P64, int nty, int seg) {
+__global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShard sh, double* __restrict__ out, int as_distance, int condensed, int P64, int nty, int seg, int nruns) {
     static_assert(MODE == S6_GCS || MODE == S6_JC || MODE == PCW_POCP || MODE == PCW_AF, "gcs, jc, pocp, af");
     constexpr bool POCP = MODE == PCW_POCP, AF = MODE == PCW_AF;
     constexpr bool VAL = POCP || AF;                                                // a hit adds a value of the source's entry, not 1
@@ -1022,9 +1022,22 @@ __global__ __launch_bounds__(64 * S7_WAVES, 8) void k_sparse_col(PcDev d, PcShar
     const int k0 = ty * S6_T;
     const int klast = min(k0 + S6_T, sh.nown) - 1;
     const int live = (pc_owned(sh, klast) + S6_T - 1) / S6_T;                      // source tiles with a pair s < t in them: s0 < the block's last target
-    const int tx1 = live - run * seg;
-    if (tx1 <= 0) return;
-    const int tx0 = max(0, tx1 - seg);
+    // Runs are ABSOLUTE ranges of source tiles: the workgroups an XCD holds at one time (consecutive blockIdx: the same run, target
+    // blocks 8 apart) stream the same `seg` source tiles, which its L2 then serves -- with runs counted from each block's own diagonal,
+    // as first built, every workgroup streamed tiles of its own and the source entries came from HBM once per TILE: 1.33 GB fetched
+    // per jc launch at N = 20,000, 2.7 GB for pocp / af; now 0.21 / 0.44 (profiles/r05/experiments/sparse_col.txt).  Order: first, for
+    // every block, the run that holds its DIAGONAL tile (pairs inside a cluster share ~85 phams: ten times the work, so they must not
+    // start last -- with them in line a jc launch at N = 3,000 took 0.058 ms instead of 0.046), then the other runs, highest tiles first:
+    // the last runs (tiles 0 .. seg - 1) are live for every target block, so the launch ends with the chip full.
+    // (... and the run below it: a cluster of 40 genomes straddles tile boundaries, so the tile next to the diagonal one is heavy too)
+    // -- taken first as well while runs are short (seg < 4: small matrices); with 8 tiles per run it mostly lies in the diagonal run, and a
+    // second diagonal-relative run would cost L2 sharing: traffic 1.34 -> 1.42 x algorithmic for pocp / af at N = 20,000, same time)
+    const int diag_run = (live - 1) / seg, early = seg < 4 ? 2 : 1;
+    const int abs_run = run < early ? diag_run - run : nruns - 1 + early - run;
+    if (abs_run < 0 || (run >= early && abs_run <= diag_run && abs_run > diag_run - early)) return;
+    const int tx0 = abs_run * seg;
+    if (tx0 >= live) return;
+    const int tx1 = min(live, tx0 + seg);
 
     // ---- once per unit: the masks over the targets
     const int gt_l = k0 + lane < sh.nown ? pc_owned(sh, k0 + lane) : -1;           // lane l <-> target row l, for the whole unit
@@ -1231,11 +1244,11 @@ int pc_launch_sparse_col(int mode, const PcDev& d, const PcShard& sh, double* ou
     int seg = (int)std::max<int64_t>(1, std::min<int64_t>(S7_SEG, live_tiles / (4 * (int64_t)(d.n_cu > 0 ? d.n_cu : 256))));
     if (const char* force = getenv("PC_COL_SEG")) { const int v = atoi(force); if (v >= 1 && v <= 64) seg = v; }
     const unsigned runs = (unsigned)((ntx + seg - 1) / seg);
-    dim3 grid(((unsigned)nty + 7u) / 8u * 8u * runs), block(64 * S7_WAVES);
-    if (mode == S6_GCS) hipLaunchKernelGGL((k_sparse_col<S6_GCS>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
-    else if (mode == PCW_POCP) hipLaunchKernelGGL((k_sparse_col<PCW_POCP>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
-    else if (mode == PCW_AF) hipLaunchKernelGGL((k_sparse_col<PCW_AF>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
-    else hipLaunchKernelGGL((k_sparse_col<S6_JC>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg);
+    dim3 grid(((unsigned)nty + 7u) / 8u * 8u * (runs + 2u)), block(64 * S7_WAVES);     // (runs 0, 1: every block's diagonal run and the one below; then the runs, highest first)
+    if (mode == S6_GCS) hipLaunchKernelGGL((k_sparse_col<S6_GCS>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg, (int)runs);
+    else if (mode == PCW_POCP) hipLaunchKernelGGL((k_sparse_col<PCW_POCP>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg, (int)runs);
+    else if (mode == PCW_AF) hipLaunchKernelGGL((k_sparse_col<PCW_AF>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg, (int)runs);
+    else hipLaunchKernelGGL((k_sparse_col<S6_JC>), grid, block, lds, st, d, sh, out, as_distance, condensed, P64, nty, seg, (int)runs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pc_set_error("k_sparse_col launch: %s", hipGetErrorString(e)); return PC_ERR_HIP; }
     return PC_OK;

@@ -14,7 +14,7 @@ t() { timeout -k 10 "$@"; }
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 if [ "$PART" = a ]; then
   bash tools/profile_round.sh ${TAG}_final 2>&1 | tail -3
-  python3 tools/summarize_profile.py k4span gpurun_out/${TAG}_final_trace_peq $OUT/bench_peq5000_k4_span.txt | tail -4
+  python3 tools/summarize_profile.py k4span gpurun_out/${TAG}_final_trace_peq $OUT/bench_peq5000_k4_span.txt gpurun_out/${TAG}_final_bench_peq5000.json | tail -4
   for n in 2000 10000 20000; do t 300 python3 -u tools/quick_bench.py -n $n --steps 3 --check 3000 2>&1 | grep --line-buffered -E "step 2|oracle" >> $OUT/sizes.txt; done; cut -c1-200 $OUT/sizes.txt
   t 200 python3 -u tools/shard_balance.py 5000 8 peq balanced 2>&1 | grep --line-buffered -v amdgpu > $OUT/shard_rehearsal_8ranks.txt; tail -2 $OUT/shard_rehearsal_8ranks.txt
   t 200 python3 -u tools/slice_scaling.py 5000 2>&1 | grep --line-buffered -v amdgpu > $OUT/slice_scaling.txt; tail -2 $OUT/slice_scaling.txt
