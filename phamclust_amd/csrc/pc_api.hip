@@ -1469,7 +1469,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
     //                    kernel in its counting mode
     //   pocp             popcount tiles + paralog excess; from ~2,500 genomes the 64 x 64 sparse tile kernel where pairs share few
     //                    enough of the phams
-    //   af               the 32 x 32 sparse tile kernel below ~1,900 genomes, the 64 x 64 one above
+    //   af               the 64 x 64 sparse tile kernel (the 32 x 32 one where that kernel's preconditions fail), the column kernel from ~1,400 genomes
     // The popcount tiles cost ~ pairs x bitmap words W, the sparse tiles ~ pairs x (a constant + the phams a pair shares).  Measured on
     // synth(5000, P), P = 300 ... 40,000, in ms: pocp 0.15 + 0.002 W against 0.207 + 0.0085 shared (sparse wins where W > 28 + 4.3 shared:
     // the synthetic collection's 79 words and 2.85 shared phams yes, 300 phams -- 5 words, 34 shared -- three times no); gcs / jc
@@ -1489,7 +1489,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         if (counts) kernel = (((double)d.Wb > 113.0 + 5.4 * shared && area >= (int64_t)3000 * 3000) ||
                               ((double)d.Wb > 60.0 + 5.4 * shared && area >= (int64_t)6000 * 6000)) ? K_SPARSE64 : K_POPC;   // (the sparse tiles gain on the popcount tiles as N grows: 5,056 phams, r04 with four workgroups per CU: N = 5,000 0.162 against 0.157 ms, 6,000 0.218 / 0.219, 7,000 0.258 / 0.282, 20,000 1.56 / 2.03)
         else if (metric == PC_POCP) kernel = (s64_ok && (double)d.Wb > 28.0 + 4.3 * shared && area >= (int64_t)2500 * 2500) ? K_SPARSE64 : K_POPC;
-        else if (s64_ok) kernel = area >= (int64_t)1900 * 1900 ? K_SPARSE64 : K_SPARSE32;
+        else if (s64_ok) kernel = K_SPARSE64;                                  // (af; r05, ms, 32 x 32 / 64 x 64 tiles: N = 200 0.060 / 0.058, 800 0.095 / 0.061, 1,300 0.082 / 0.069 -- since r04's dense broadcast path the larger tile wins at every size)
         else kernel = area > (int64_t)3500 * 3500 ? K_WALKER : K_SPARSE32;
         // r05: gcs / jc / pocp: the column form of the counting mode (k_sparse_col: the masks over a block of targets stay in LDS for a run
         // of source tiles, no barrier per tile) -- while its masks (pocp: and its paralog list and bit sets) fit 78 KB of LDS.  Against the popcount tiles
@@ -1508,7 +1508,7 @@ static int fill_impl(pc_ctx* c, int metric, int as_distance, double* out, int co
         }
         // (ms, popcount tiles / 64 x 64 sparse tiles / column -- pocp: N = 2,000 0.066 / 0.082 / 0.078, 3,000 0.137 / 0.118 / 0.083, 5,000 0.304 / 0.217 / 0.156,
         // 20,000 3.89 / 2.23 / 1.45; af: 2,000 - / 0.089 / 0.078, 3,000 - / 0.121 / 0.081, 5,000 - / 0.258 / 0.150, 20,000 - / 2.41 / 1.42)
-        const int64_t col_min_n = metric == PC_AF ? 1800 : PC_COL_MIN_N;
+        const int64_t col_min_n = metric == PC_AF ? 1400 : PC_COL_MIN_N;        // (af, 64 x 64 tiles / column: N = 1,000 0.062 / 0.072, 1,300 0.069 / 0.073, 1,500 0.087 / 0.074, 1,800 0.088 / 0.077)
         if (col_ok && (double)d.Wb > 40.0 + 8.0 * shared && area >= col_min_n * col_min_n) kernel = K_SPARSE_COL;
         if (set_force) {
             if (!strcmp(set_force, "sparsecol") && col_ok) kernel = K_SPARSE_COL;

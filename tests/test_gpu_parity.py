@@ -1870,3 +1870,39 @@ def test_column_kernel_value_modes(gpu_ctx, native_built):
         assert np.array_equal(gpu_ctx.fill("pocp"), O.fill(longish, "pocp")) and gpu_ctx.last_set_kernel() == "sparsecol"
     finally:
         os.environ.pop("PC_SET_KERNEL", None)
+
+
+@pytest.mark.parametrize("n_genomes", [2, 3, 63, 64, 65, 129, 200])
+def test_column_kernel_edge_sizes(gpu_ctx, native_built, n_genomes):
+    """k_sparse_col at the edges of its tiling (blocks and tiles of 64 genomes; 16 waves x 4 rows): fewer genomes than a tile, exactly one,
+    one more, a ragged last block -- all four set metrics, similarity and distance, unsharded and as the shards of a 2-rank deal, every
+    value against the oracle (metrics.py:26-157), with the kernel forced (the selector would not pick it at these sizes)."""
+    import torch
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(n_genomes, 700, seed=100 + n_genomes)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        os.environ["PC_SET_KERNEL"] = "sparsecol"
+        gpu_ctx.upload(packed, residues=False)
+        for m in SET_METRICS:
+            for dist in (True, False):
+                assert np.array_equal(gpu_ctx.fill(m, dist), O.fill(packed, m, dist)), (m, dist)
+                assert gpu_ctx.last_set_kernel() == "sparsecol", m
+        n = packed.n_genomes
+        for rank in range(2):
+            gpu_ctx.set_shard(rank, 2)
+            t_rank, t_lbase = gpu_ctx.shard_table()
+            for m in SET_METRICS:
+                want = O.fill(packed, m, True)
+                buf = torch.full((max(gpu_ctx.shard_stride(), 1),), -1.0, dtype=torch.float64, device="cuda:0")
+                gpu_ctx.fill_shard_dev(m, True, buf.data_ptr(), stream)
+                torch.cuda.synchronize()
+                got = buf.cpu().numpy()
+                for t in range(1, n):
+                    if t_rank[t] == rank:
+                        col = np.array([want[s * n - s * (s + 1) // 2 + (t - s - 1)] for s in range(t)])
+                        assert np.array_equal(got[t_lbase[t]:t_lbase[t] + t], col), (m, rank, t)
+        gpu_ctx.set_shard(0, 1)
+    finally:
+        os.environ.pop("PC_SET_KERNEL", None)
