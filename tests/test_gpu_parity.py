@@ -510,9 +510,9 @@ def test_strip_mined_long_column_genes(gpu_ctx, native_built):
                     assert np.array_equal(gpu_ctx.fill(metric), want_fill[metric]), f"rule {rule} {metric} PC_PIPE {pipe}"
             os.environ.pop("PC_PIPE", None)
             if rule == 0:
-                sel = (lens_all[b] < 5500) & (lens_all[a] < 5500)          # the one-lane-per-alignment kernel agrees (it stays as the fallback;
-                ident, diag = gpu_ctx.align_pairs(a[sel], b[sel], variant=-1)   # 3 x 10^7 cells on ONE lane take seconds: only the shorter pairs)
-                assert sel.sum() >= 10 and np.array_equal(ident, wi[sel]) and np.array_equal(diag, wd[sel])
+                sel = (lens_all[b] < 4200) & (lens_all[a] < 5500)          # the one-lane-per-alignment kernel agrees (it stays as the fallback;
+                ident, diag = gpu_ctx.align_pairs(a[sel], b[sel], variant=-1)   # 2 x 10^7 cells on ONE lane take seconds: only the 4,097-column pairs)
+                assert sel.sum() >= 4 and np.array_equal(ident, wi[sel]) and np.array_equal(diag, wd[sel])
             # percent-positives: the profile cell, passes of 64 x 24 columns, for column genes of 1,537 ... 8,191 residues
             gpu_ctx.upload(pk_ppos)
             assert np.array_equal(gpu_ctx.fill("aai_ppos"), O.fill(pk_ppos, "aai_ppos")), f"rule {rule} aai_ppos"
@@ -1605,7 +1605,7 @@ with hip.Context(0) as ctx:
     assert np.array_equal(ctx.fill("aai"), O.fill(pk, "aai"))
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_RAW_STAGE_MAX="0"), capture_output=True, text=True, timeout=600)
+    run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_RAW_STAGE_MAX="0", PHAMCLUST_NO_TORCH="1"), capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
 
 
