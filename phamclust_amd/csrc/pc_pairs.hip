@@ -968,8 +968,8 @@ int pc_launch_sparse64(int mode, const PcDev& d, const PcShard& sh, double* out,
 }
 
 // ---------------------------------------------------------------------------------
-// K1 for large matrices (r05): gcs / jc with the masks over a block of 64 TARGET genomes kept in LDS across a run of source tiles,
-// and every accumulator row owned by ONE wave -- no barrier per tile.
+// K1 / K2 for large matrices (r05): all four set metrics with the masks over a block of 64 TARGET genomes kept in LDS across a run of
+// source tiles, and every accumulator row owned by ONE wave -- no barrier per tile.  (metrics.py:26-157)
 //
 // What the r05 split of k_sparse_tile64's counting mode showed (profiles/r05/experiments/set_tile_time_split.txt, sparse_col.txt;
 // N = 20,000, 1.51 ms): 0.75 ms of a launch is neither probing nor the epilogue but what a tile does before it can probe -- per mask
