@@ -1906,3 +1906,33 @@ def test_column_kernel_edge_sizes(gpu_ctx, native_built, n_genomes):
         gpu_ctx.set_shard(0, 1)
     finally:
         os.environ.pop("PC_SET_KERNEL", None)
+
+
+def test_column_kernel_at_20000_genomes(gpu_ctx, native_built):
+    """The size the column kernel exists for: synth(20000, 5000), 199,990,000 pairs per metric.  Its matrix (the selector's own choice
+    there) must equal, value for value, the matrix of an independent kernel family -- the 64 x 64 sparse tiles for all four metrics,
+    the popcount tiles as well for jc -- and 100,000 random pairs per metric must equal the oracle (metrics.py:26-157)."""
+    from phamclust_amd.synth import synth_packed
+    O = _oracle()
+    packed = synth_packed(20000, 5000)
+    n = packed.n_genomes
+    gpu_ctx.upload(packed, residues=False)
+    rng = np.random.default_rng(2020)
+    a, b = rng.integers(0, n, 100000), rng.integers(0, n, 100000)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    keep = lo < hi
+    lo, hi = lo[keep], hi[keep]
+    idx = lo * n - lo * (lo + 1) // 2 + (hi - lo - 1)
+    try:
+        for m in SET_METRICS:
+            os.environ.pop("PC_SET_KERNEL", None)
+            got = np.asarray(gpu_ctx.fill(m, borrow=True)).copy()
+            assert gpu_ctx.last_set_kernel() == "sparsecol" and got.shape == (n * (n - 1) // 2,)
+            assert np.array_equal(got[idx], O.pairs(packed, m, lo, hi, as_distance=True)), m
+            for other in ("sparse64",) + (("popc",) if m == "jc" else ()):
+                os.environ["PC_SET_KERNEL"] = other
+                ref = gpu_ctx.fill(m, borrow=True)
+                assert gpu_ctx.last_set_kernel() == other
+                assert np.array_equal(got, np.asarray(ref)), (m, other)
+    finally:
+        os.environ.pop("PC_SET_KERNEL", None)
