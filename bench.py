@@ -340,7 +340,7 @@ def aligned_roofline(a, world, n_aln, n_cells, n_rbytes, n_daln, n_dcells, ms_al
         "kernel": "k_nw_systolic_tier<TIER,RULE,cell> / k_nw_systolic<W,RULE> (all launches of one fill, per GPU)",
         "instr_per_cell": instr_per_cell, "issue_clk_per_cell": issue_clk_per_cell, "peak_gcups": peak_gcups, "achieved_gcups": gcups,
         "frac_at_4_clk_per_instruction": gcups / (256 * 4 * 16 * 2.4e9 / instr_per_cell / 1e9),
-        "issue_rate_source": "profiles/valu_issue_rate.json (unmixed: 4.15 / 2.15 clk), profiles/r04/final/counters.json (11.49 executed VALU instructions per cell), "
+        "issue_rate_source": "profiles/valu_issue_rate.json (unmixed: 4.15 / 2.15 clk), profiles/r05/final/counters.json (11.49 executed VALU instructions per cell), "
                              "profiles/r04/experiments/retag_one_op_ab.txt, valu_mix_probe.txt",
         "ms_kernels_per_fill": ms_align, "n_alignments": n_aln, "dp_cells": n_cells,
         # what the kernels computed: identical (row sequence, column sequence) pairs are aligned once per rank

@@ -177,7 +177,7 @@ int pc_nw_choose_variant(int lb) {
         // measure 1.9-2.2 TCUPS at full lane use (profiles/r01/experiments/o_wide_variant_gcups.txt): one wave can keep its
         // SIMD's VALU busy, so the penalty is small
         const double pen = W >= 64 ? 1.15 : W >= 48 ? 1.08 : W >= 32 ? 1.04 : W >= 24 ? 1.022 : (W >= 22 ? 1.014 : 1.0);
-        // constants of the cost model; their sweeps came out flat (profiles/r02/experiments, r04: tools/r04 choose_sweep records) and the
+        // constants of the cost model; their sweeps came out flat (profiles/r02/experiments, profiles/r04/experiments/choose_sweep_after_retag.txt) and the
         // environment knobs that drove them (PC_CHOOSE_C0 / _C1 / _CELL) are gone (r05)
         constexpr double c0 = 0.3, c1 = 0.535;
         constexpr double cell = 0.94;  // relative cost of the 10-instruction cell's classes (sweep 1.0 / 0.96 / 0.93 / 0.90: 239.6 / 237.8 / 238.1 / 237.9 ms at N=3,000)
