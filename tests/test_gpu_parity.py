@@ -923,6 +923,7 @@ def test_bench_json_contract(native_built):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["verified"]["bit_exact"] is True and d["value"] > 0
+    assert d["value_resident"] == d["value"] and 0 < d["value_wall"] <= d["value"] and "SURVEY 8(d)" in d["value_definition"]
 
 
 def test_bench_two_ranks_rehearsal(native_built):
