@@ -1090,6 +1090,23 @@ static int run_align_classes(pc_ctx* c, const PcTask* task_list, const uint32_t*
         if (g == groups.size()) groups.push_back({key, {}});
         groups[g].members.push_back(i);
     }
+    // Launches of little work (fewer wave-tasks than four rounds of the chip's wave slots: a fill has two dozen, a millisecond or less
+    // each) are ISSUED first: at the head of the streams they are done within the fill's first milliseconds.  In the order above the
+    // last of them sat behind the launch that runs for most of the fill, in its hardware queue, and ran one after the other on an
+    // empty chip when it ended -- the fill's fixed cost (profiles/r05/experiments/k4_fill_timeline.txt: 3.2 ms at N = 5,000, 2.6 of a
+    // 75-ms rank of the 8-rank shard).  Worth -0.5 % at N = 2,000, nothing at 5,000, -1.0 % for that rank: T(w) = 3.3 + 548 / w.
+    {
+        const uint64_t small_below = (uint64_t)4 * 32 * (uint64_t)(c->n_cu > 0 ? c->n_cu : 256);
+        std::stable_partition(groups.begin(), groups.end(), [&](const Group& grp) {
+            uint64_t wave_tasks = 0;
+            for (int i : grp.members) {
+                const Launch& l = launches[i];
+                if (region[i].bytes) return false;                             // (launches on the scratch slab keep their place)
+                wave_tasks += (uint64_t)(l.end - l.begin) * (l.mode == PC_MODE_ONE_WAVE ? 1u : l.mode == PC_MODE_TWO_WAVES ? 2u : 4u);
+            }
+            return wave_tasks < small_below;
+        });
+    }
     constexpr int kAux = pc_ctx::kAux;
     const int n_aux = std::min((int)groups.size(), c->n_streams) - 1;        // auxiliary streams this fill uses
     int n_long = 0;                                                          // launches with a scratch region of their own: on the long-task streams
