@@ -1606,7 +1606,7 @@ with hip.Context(0) as ctx:
     assert np.array_equal(ctx.fill("aai"), O.fill(pk, "aai"))
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_RAW_STAGE_MAX="0", PHAMCLUST_NO_TORCH="1"), capture_output=True, text=True, timeout=600)
+    run = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_RAW_STAGE_MAX="0"), capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
 
 
